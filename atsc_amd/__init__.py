@@ -1,0 +1,189 @@
+"""atsc_amd -- MI355X-native ATSC 8VSB modulator hot path.
+
+The product is the C-ABI shared library ``atsc_amd/lib/libatsc_hip.so`` (HIP kernels for gfx950,
+sources in ``atsc_amd/csrc``; C++ adapter with the reference's ``atsc::atsc_encoder`` shape in
+``atsc_amd/host``).  This Python module is only a thin ctypes binding used by the tests and by
+``bench.py``; it contains no compute and has NO CPU fallback: if the library is missing, or no GPU
+is present, every entry point raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(ROOT, "atsc_amd", "lib", "libatsc_hip.so")
+
+PACKETS_PER_FIELD = 312
+TS_PACKET_BYTES = 188
+FIELD_TS_BYTES = 312 * 188
+FIELD_CODED_BYTES = 312 * 207
+FIELD_SYMBOLS = 313 * 832
+FIELD_IQ_BYTES = FIELD_SYMBOLS * 8
+PADDED_SYMBOLS = 314 * 832
+INTERLEAVER_TAIL = 10608
+SYMBOL_RATE = 4500000.0 / 286 * 684  # 10.762238 MHz, one real-time channel
+
+FLAG_TIMING = 1
+(STAGE_RAND_RS, STAGE_INTERLEAVE, STAGE_TRELLIS_PAR, STAGE_TRELLIS_SCAN, STAGE_TRELLIS_MAP, STAGE_MIX_FIR,
+ STAGE_STATE, NSTAGES) = range(8)
+STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trellis_map", "mix_fir", "save_state")
+
+# every symbol include/atsc_hip.h declares
+EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_encode_batch",
+           "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_export_state", "atsc_hip_import_state",
+           "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_get_table",
+           "atsc_hip_error_string", "atsc_hip_version")
+
+
+class AtscHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("channels", C.c_int), ("max_fields", C.c_int), ("flags", C.c_int)]
+
+
+class StreamState(C.Structure):
+    _fields_ = [("field_index", C.c_uint64), ("coded_tail", C.c_uint8 * INTERLEAVER_TAIL),
+                ("last_group", C.c_uint8 * 12), ("z2", C.c_uint8 * 12), ("z0_next", C.c_uint8 * 12),
+                ("z0_prev", C.c_uint8 * 12)]
+
+
+FIELD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint)
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "atsc_amd", "csrc")], capture_output=True, text=True)
+    if verbose or out.returncode:
+        print(out.stdout, out.stderr)
+    if out.returncode:
+        raise AtscHipError("building libatsc_hip.so failed")
+    return LIB_PATH
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AtscHipError(f"{LIB_PATH} is missing: run __graft_entry__.build() (there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u8p = C.c_void_p, C.c_void_p
+    L.atsc_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.atsc_hip_destroy.argtypes = [vp]
+    L.atsc_hip_destroy.restype = None
+    L.atsc_hip_process.argtypes = [vp, u8p, C.c_uint, FIELD_CB, vp]
+    L.atsc_hip_encode_batch.argtypes = [vp, u8p, C.c_int, u8p, vp, vp]
+    L.atsc_hip_encode_batch_host.argtypes = [vp, u8p, C.c_int, u8p, vp]
+    L.atsc_hip_mix_fir.argtypes = [vp, u8p, C.c_int, vp, vp]
+    L.atsc_hip_export_state.argtypes = [vp, C.c_int, C.POINTER(StreamState)]
+    L.atsc_hip_import_state.argtypes = [vp, C.c_int, C.POINTER(StreamState)]
+    L.atsc_hip_span_parity.argtypes = [vp, C.c_int, u8p]
+    L.atsc_hip_stage_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.atsc_hip_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    L.atsc_hip_get_table.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.atsc_hip_error_string.argtypes = [C.c_int]
+    L.atsc_hip_error_string.restype = C.c_char_p
+    L.atsc_hip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise AtscHipError(f"atsc_hip error {rc}: {load_library().atsc_hip_error_string(rc).decode()}")
+
+
+class Encoder:
+    """Host mirror of ``atsc::atsc_encoder`` (reference: src/atsc/atsc.h:7-16) plus the batched entry points.
+
+    ``process(pkts, count, fn)`` has the reference's semantics; ``encode_batch`` takes device pointers
+    (ints, e.g. ``tensor.data_ptr()``) and is asynchronous on ``stream``.
+    """
+
+    def __init__(self, channels=1, max_fields=1, device=0, timing=False):
+        self.L = load_library()
+        self.channels, self.max_fields, self.device = channels, max_fields, device
+        cfg = Config(device, channels, max_fields, FLAG_TIMING if timing else 0)
+        h = C.c_void_p()
+        check(self.L.atsc_hip_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def create(cls, **kw):
+        return cls(**kw)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.atsc_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ---- reference-shaped streaming path
+    def process(self, pkts, count, fn):
+        """pkts: bytes-like / numpy u8 of count*188 bytes; fn(iq_ptr:int, nbytes:int) per completed field."""
+        import numpy as np
+        buf = np.ascontiguousarray(np.frombuffer(pkts, dtype=np.uint8) if not isinstance(pkts, np.ndarray) else pkts)
+        assert buf.size >= count * TS_PACKET_BYTES
+        cb = FIELD_CB(lambda user, iq, nbytes: fn(iq, nbytes))
+        check(self.L.atsc_hip_process(self.h, buf.ctypes.data, count, cb, None))
+
+    # ---- batched device path
+    def encode_batch(self, d_ts, fields, d_sym=None, d_iq=None, stream=None):
+        check(self.L.atsc_hip_encode_batch(self.h, d_ts, fields, d_sym, d_iq, stream))
+
+    def mix_fir(self, d_sym, fields, d_iq, stream=None):
+        check(self.L.atsc_hip_mix_fir(self.h, d_sym, fields, d_iq, stream))
+
+    def encode_batch_host(self, ts, fields, want_sym=True, want_iq=True):
+        import numpy as np
+        ts = np.ascontiguousarray(ts, np.uint8)
+        assert ts.size == self.channels * fields * FIELD_TS_BYTES
+        sym = np.empty(self.channels * fields * FIELD_SYMBOLS, np.uint8) if want_sym else None
+        iq = np.empty(self.channels * fields * FIELD_SYMBOLS, np.complex64) if want_iq else None
+        check(self.L.atsc_hip_encode_batch_host(self.h, ts.ctypes.data, fields, sym.ctypes.data if want_sym else None,
+                                                iq.ctypes.data if want_iq else None))
+        return sym, iq
+
+    # ---- state, taps, timings
+    def export_state(self, channel=0):
+        st = StreamState()
+        check(self.L.atsc_hip_export_state(self.h, channel, C.byref(st)))
+        return st
+
+    def import_state(self, st, channel=0):
+        check(self.L.atsc_hip_import_state(self.h, channel, C.byref(st)))
+
+    def span_parity(self, channel=0):
+        import numpy as np
+        out = np.zeros(36, np.uint8)
+        check(self.L.atsc_hip_span_parity(self.h, channel, out.ctypes.data))
+        return out.reshape(3, 12)
+
+    def stage_buffer(self, stage):
+        p, n, st = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        check(self.L.atsc_hip_stage_buffer(self.h, stage, C.byref(p), C.byref(n), C.byref(st)))
+        return p.value, n.value, st.value
+
+    def last_timings(self):
+        ms = (C.c_float * NSTAGES)()
+        check(self.L.atsc_hip_last_timings(self.h, ms))
+        return {STAGE_NAMES[i]: ms[i] for i in range(NSTAGES)}
+
+    def table(self, which):
+        return get_table(which, self.h)
+
+
+def get_table(which, handle=None):
+    """Constant tables as the library builds them (no GPU needed when handle is None)."""
+    import numpy as np
+    shapes = {0: (112, np.float32), 1: (PADDED_SYMBOLS * 2, np.float32), 2: (2, np.float32),
+              3: (187 * 312, np.uint8), 4: (820, np.uint8), 5: (820, np.uint8), 6: (21, np.uint8)}
+    n, dt = shapes[which]
+    out = np.zeros(n, dt)
+    check(load_library().atsc_hip_get_table(handle, which, out.ctypes.data, out.nbytes))
+    return out

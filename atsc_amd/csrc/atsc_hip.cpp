@@ -1,0 +1,421 @@
+// C-ABI host layer of the MI355X 8VSB modulator (see include/atsc_hip.h).
+// Mirrors atsc_encoder_impl (reference: src/atsc/atsc.cpp:15-91): packet buffering, field
+// sequencing, per-field callbacks -- with the seven stages replaced by batched gfx950 kernels.
+#include "atsc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+#include "tables.h"
+
+using namespace atsc_k;
+
+#define HIP_TRY(expr)                                  \
+    do {                                               \
+        hipError_t _e = (expr);                        \
+        if (_e != hipSuccess) return static_cast<int>(_e); \
+    } while (0)
+
+namespace {
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}  // namespace
+
+struct atsc_hip_encoder {
+    atsc_hip_config cfg{};
+    atsc_tables::Tables tab;
+    DeviceTables dtab{};
+    Buffers buf{};
+    uint8_t* d_sym = nullptr;   // internal symbol buffer [channels][max_fields][260416]
+    size_t sym_stride = 0;
+    float2* d_osc[2] = {nullptr, nullptr};
+    int osc_cur = 0;
+    float2 scale{};
+    uint64_t field_index = 0;
+    int last_fields = 0;       // field count of the last batch (internal symbol buffer is packed with it)
+    void* d_tables = nullptr;
+
+    // streaming path (1 channel)
+    std::vector<uint8_t> pending;        // bytes of an incomplete field + queued whole fields
+    uint8_t* h_ts_pinned = nullptr;
+    uint8_t* d_ts = nullptr;
+    float2* d_iq = nullptr;
+    float2* h_iq_pinned = nullptr;
+
+    // timing
+    hipEvent_t ev[ATSC_HIP_NSTAGES + 1] = {};
+    bool ev_valid = false;
+    bool ev_recorded[ATSC_HIP_NSTAGES + 1] = {};
+};
+
+extern "C" const char* atsc_hip_version(void) { return "atsc_hip 0.1 (gfx950)"; }
+
+extern "C" const char* atsc_hip_error_string(int code) {
+    switch (code) {
+        case ATSC_HIP_OK: return "ok";
+        case ATSC_HIP_ERR_ARG: return "invalid argument";
+        case ATSC_HIP_ERR_NO_DEVICE: return "no HIP device: the 8VSB path has no CPU fallback";
+        case ATSC_HIP_ERR_TOO_LARGE: return "batch larger than the handle was created for";
+        case ATSC_HIP_ERR_STATE: return "call not valid in this state";
+        default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown error";
+    }
+}
+
+static int destroy_impl(atsc_hip_encoder* e) {
+    if (!e) return 0;
+    hipSetDevice(e->cfg.device);
+    hipFree(e->buf.coded); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
+    hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
+    hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_tables);
+    hipFree(e->d_ts); hipFree(e->d_iq);
+    if (e->h_ts_pinned) hipHostFree(e->h_ts_pinned);
+    if (e->h_iq_pinned) hipHostFree(e->h_iq_pinned);
+    if (e->ev_valid)
+        for (auto& ev : e->ev) hipEventDestroy(ev);
+    delete e;
+    return 0;
+}
+
+extern "C" void atsc_hip_destroy(atsc_hip_encoder* enc) { destroy_impl(enc); }
+
+extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
+    if (!cfg || !out || cfg->channels < 1 || cfg->max_fields < 1) return ATSC_HIP_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ATSC_HIP_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    auto* e = new (std::nothrow) atsc_hip_encoder();
+    if (!e) return ATSC_HIP_ERR_ARG;
+    e->cfg = *cfg;
+    atsc_tables::build(e->tab);
+    const size_t C = cfg->channels, F = cfg->max_fields;
+
+#define TRY_OR_FREE(expr)                                \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) { destroy_impl(e); return static_cast<int>(_e); } \
+    } while (0)
+
+    // constant tables: one allocation [prbs188 | rs_rows | fsync even | fsync odd]
+    const size_t off_prbs = 0, off_rows = align_up(kFieldTs, 256), off_fs = off_rows + 256 * 32;
+    const size_t tab_bytes = off_fs + 2 * kSegSyms;
+    TRY_OR_FREE(hipMalloc(&e->d_tables, tab_bytes));
+    {
+        std::vector<uint8_t> h(tab_bytes, 0);
+        std::memcpy(h.data() + off_prbs, e->tab.prbs188.data(), kFieldTs);
+        std::memcpy(h.data() + off_rows, e->tab.rs_rows.data(), 256 * 32);
+        std::memcpy(h.data() + off_fs, e->tab.fsync[0].data(), kSegSyms);
+        std::memcpy(h.data() + off_fs + kSegSyms, e->tab.fsync[1].data(), kSegSyms);
+        TRY_OR_FREE(hipMemcpy(e->d_tables, h.data(), tab_bytes, hipMemcpyHostToDevice));
+    }
+    auto* tb = static_cast<uint8_t*>(e->d_tables);
+    e->dtab.prbs188 = reinterpret_cast<const uint32_t*>(tb + off_prbs);
+    e->dtab.rs_rows = reinterpret_cast<const uint4*>(tb + off_rows);
+    e->dtab.fsync = tb + off_fs;
+    TRY_OR_FREE(upload_taps(e->tab.taps));
+
+    // per-channel working buffers
+    e->buf.max_fields = cfg->max_fields;
+    e->buf.coded_stride = align_up(kTail + F * kFieldCoded, 256);
+    e->buf.il_stride = align_up(F * kFieldCoded, 256);
+    e->sym_stride = F * kFieldSyms;
+    TRY_OR_FREE(hipMalloc(&e->buf.coded, C * e->buf.coded_stride));
+    TRY_OR_FREE(hipMalloc(&e->buf.il, C * e->buf.il_stride));
+    TRY_OR_FREE(hipMalloc(&e->buf.par, C * F * kParts * sizeof(uint4)));
+    TRY_OR_FREE(hipMalloc(&e->buf.cin, C * F * kParts * sizeof(uint4)));
+    TRY_OR_FREE(hipMalloc(&e->buf.carry, C * sizeof(uint4)));
+    TRY_OR_FREE(hipMalloc(&e->buf.span_par, C * sizeof(uint4)));
+    TRY_OR_FREE(hipMalloc(&e->buf.last_group, C * 16));
+    TRY_OR_FREE(hipMalloc(&e->d_sym, C * e->sym_stride));
+    // zero history (reference: atsc.cpp:24-26,34; trellis.h:55-59)
+    TRY_OR_FREE(hipMemset(e->buf.coded, 0, C * e->buf.coded_stride));
+    TRY_OR_FREE(hipMemset(e->buf.carry, 0, C * sizeof(uint4)));
+    TRY_OR_FREE(hipMemset(e->buf.span_par, 0, C * sizeof(uint4)));
+    TRY_OR_FREE(hipMemset(e->buf.last_group, 0, C * 16));
+
+    // oscillator state (double-buffered), T_0 and the per-field rotation
+    for (int i = 0; i < 2; ++i) TRY_OR_FREE(hipMalloc(&e->d_osc[i], sizeof(float2) * kPaddedSyms));
+    TRY_OR_FREE(hipMemcpy(e->d_osc[0], e->tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice));
+    e->scale = make_float2(e->tab.scale[0], e->tab.scale[1]);
+
+    if (cfg->flags & ATSC_HIP_FLAG_TIMING) {
+        for (auto& ev : e->ev) TRY_OR_FREE(hipEventCreate(&ev));
+        e->ev_valid = true;
+    }
+    TRY_OR_FREE(hipDeviceSynchronize());
+#undef TRY_OR_FREE
+    *out = e;
+    return ATSC_HIP_OK;
+}
+
+namespace {
+
+void mark(atsc_hip_encoder* e, hipStream_t s, int idx) {
+    if (e->ev_valid) {
+        hipEventRecord(e->ev[idx], s);
+        e->ev_recorded[idx] = true;
+    }
+}
+
+// stages a2..a6 (reference: atsc.cpp:80-84) for `fields` fields of every channel
+int run_symbols(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, uint8_t* d_sym, size_t sym_stride, hipStream_t s) {
+    const int C = e->cfg.channels;
+    mark(e, s, ATSC_HIP_STAGE_RAND_RS);
+    launch_rand_rs(s, e->dtab, d_ts, (size_t)fields * kFieldTs, e->buf, C, fields);
+    mark(e, s, ATSC_HIP_STAGE_INTERLEAVE);
+    launch_interleave(s, e->buf, C, fields);
+    mark(e, s, ATSC_HIP_STAGE_TRELLIS_PAR);
+    launch_trellis_parity(s, e->buf, C, fields);
+    mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);
+    launch_trellis_scan(s, e->buf, C, fields);
+    mark(e, s, ATSC_HIP_STAGE_TRELLIS_MAP);
+    launch_trellis_map(s, e->dtab, e->buf, d_sym, sym_stride, C, fields, e->field_index);
+    return static_cast<int>(hipGetLastError());
+}
+
+int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, void* d_iq, int fields, hipStream_t s) {
+    const int C = e->cfg.channels;
+    mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
+    const float2* oin = e->d_osc[e->osc_cur];
+    float2* oout = e->d_osc[e->osc_cur ^ 1];
+    if (d_iq)
+        launch_mix_fir(s, d_sym, sym_stride, static_cast<float2*>(d_iq), (size_t)fields * kFieldSyms, oin, oout, e->scale,
+                       C, fields);
+    else
+        launch_osc_advance(s, oin, oout, e->scale, (unsigned)fields);
+    e->osc_cur ^= 1;
+    return static_cast<int>(hipGetLastError());
+}
+
+}  // namespace
+
+extern "C" int atsc_hip_encode_batch(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, uint8_t* d_sym, void* d_iq,
+                                     void* stream) {
+    if (!e || !d_ts || fields < 1) return ATSC_HIP_ERR_ARG;
+    if (fields > e->cfg.max_fields) return ATSC_HIP_ERR_TOO_LARGE;
+    if ((reinterpret_cast<uintptr_t>(d_ts) & 3) || (reinterpret_cast<uintptr_t>(d_sym) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_iq) & 15))
+        return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    auto s = static_cast<hipStream_t>(stream);
+    uint8_t* sym = d_sym ? d_sym : e->d_sym;
+    e->last_fields = fields;
+    const size_t sym_stride = (size_t)fields * kFieldSyms;
+    std::fill(std::begin(e->ev_recorded), std::end(e->ev_recorded), false);
+    int rc = run_symbols(e, d_ts, fields, sym, sym_stride, s);
+    if (rc) return rc;
+    rc = run_mix_fir(e, sym, sym_stride, d_iq, fields, s);
+    if (rc) return rc;
+    mark(e, s, ATSC_HIP_STAGE_STATE);
+    launch_save_state(s, e->buf, e->cfg.channels, fields);
+    mark(e, s, ATSC_HIP_NSTAGES);
+    e->field_index += (uint64_t)fields;
+    return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int atsc_hip_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, int fields, void* d_iq, void* stream) {
+    if (!e || !d_sym || !d_iq || fields < 1) return ATSC_HIP_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_sym) & 15) || (reinterpret_cast<uintptr_t>(d_iq) & 15)) return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    auto s = static_cast<hipStream_t>(stream);
+    std::fill(std::begin(e->ev_recorded), std::end(e->ev_recorded), false);
+    int rc = run_mix_fir(e, d_sym, (size_t)fields * kFieldSyms, d_iq, fields, s);
+    mark(e, s, ATSC_HIP_STAGE_STATE);
+    if (rc) return rc;
+    e->field_index += (uint64_t)fields;
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_encode_batch_host(atsc_hip_encoder* e, const uint8_t* h_ts, int fields, uint8_t* h_sym,
+                                          void* h_iq) {
+    if (!e || !h_ts || fields < 1) return ATSC_HIP_ERR_ARG;
+    if (fields > e->cfg.max_fields) return ATSC_HIP_ERR_TOO_LARGE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t C = e->cfg.channels;
+    const size_t ts_bytes = C * fields * kFieldTs, sym_bytes = C * fields * kFieldSyms;
+    uint8_t* d_ts = nullptr;
+    void* d_iq = nullptr;
+    HIP_TRY(hipMalloc(&d_ts, ts_bytes));
+    int rc = static_cast<int>(hipMemcpy(d_ts, h_ts, ts_bytes, hipMemcpyHostToDevice));
+    if (!rc && h_iq) rc = static_cast<int>(hipMalloc(&d_iq, sym_bytes * 8));
+    if (!rc) rc = atsc_hip_encode_batch(e, d_ts, fields, nullptr, d_iq, nullptr);
+    if (!rc) rc = static_cast<int>(hipDeviceSynchronize());
+    if (!rc && h_sym) {
+        // internal symbol buffer is packed with the batch's own field count
+        rc = static_cast<int>(hipMemcpy(h_sym, e->d_sym, sym_bytes, hipMemcpyDeviceToHost));
+    }
+    if (!rc && h_iq) rc = static_cast<int>(hipMemcpy(h_iq, d_iq, sym_bytes * 8, hipMemcpyDeviceToHost));
+    hipFree(d_ts);
+    hipFree(d_iq);
+    return rc;
+}
+
+// Streaming path: reference semantics of atsc_encoder_impl::process (atsc.cpp:59-77).
+extern "C" int atsc_hip_process(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb,
+                                void* user) {
+    if (!e || (!h_pkts && count)) return ATSC_HIP_ERR_ARG;
+    if (e->cfg.channels != 1) return ATSC_HIP_ERR_STATE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t F = e->cfg.max_fields;
+    if (!e->d_ts) {
+        HIP_TRY(hipMalloc(&e->d_ts, F * kFieldTs));
+        HIP_TRY(hipMalloc(&e->d_iq, F * kFieldSyms * sizeof(float2)));
+        HIP_TRY(hipHostMalloc(&e->h_ts_pinned, F * kFieldTs, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&e->h_iq_pinned, F * kFieldSyms * sizeof(float2), hipHostMallocDefault));
+    }
+    // copy-before-return contract (atsc.cpp:66)
+    e->pending.insert(e->pending.end(), h_pkts, h_pkts + (size_t)count * ATSC_HIP_TS_PACKET_BYTES);
+    size_t done = 0;
+    while (e->pending.size() - done >= (size_t)kFieldTs) {
+        const int nf = (int)std::min<size_t>((e->pending.size() - done) / kFieldTs, F);
+        std::memcpy(e->h_ts_pinned, e->pending.data() + done, (size_t)nf * kFieldTs);
+        HIP_TRY(hipMemcpyAsync(e->d_ts, e->h_ts_pinned, (size_t)nf * kFieldTs, hipMemcpyHostToDevice, nullptr));
+        int rc = atsc_hip_encode_batch(e, e->d_ts, nf, nullptr, e->d_iq, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(e->h_iq_pinned, e->d_iq, (size_t)nf * kFieldSyms * sizeof(float2), hipMemcpyDeviceToHost,
+                               nullptr));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+        done += (size_t)nf * kFieldTs;
+        if (cb)
+            for (int f = 0; f < nf; ++f) cb(user, e->h_iq_pinned + (size_t)f * kFieldSyms, ATSC_HIP_FIELD_IQ_BYTES);
+    }
+    e->pending.erase(e->pending.begin(), e->pending.begin() + done);
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_export_state(atsc_hip_encoder* e, int channel, atsc_hip_stream_state* out) {
+    if (!e || !out || channel < 0 || channel >= e->cfg.channels) return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::memset(out, 0, sizeof *out);
+    out->field_index = e->field_index;
+    HIP_TRY(hipMemcpy(out->coded_tail, e->buf.coded + (size_t)channel * e->buf.coded_stride, kTail, hipMemcpyDeviceToHost));
+    uint8_t lg[16];
+    HIP_TRY(hipMemcpy(lg, e->buf.last_group + (size_t)channel * 16, 16, hipMemcpyDeviceToHost));
+    std::memcpy(out->last_group, lg, 12);
+    uint32_t cw[4];
+    HIP_TRY(hipMemcpy(cw, e->buf.carry + channel, 16, hipMemcpyDeviceToHost));
+    for (int en = 0; en < 12; ++en) {
+        const uint32_t b = (cw[en / 4] >> (8 * (en % 4))) & 0xff;
+        out->z2[en] = b & 1;
+        out->z0_next[en] = (b >> 1) & 1;
+        out->z0_prev[en] = (b >> 2) & 1;
+    }
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_import_state(atsc_hip_encoder* e, int channel, const atsc_hip_stream_state* in) {
+    if (!e || !in || channel < 0 || channel >= e->cfg.channels) return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(e->buf.coded + (size_t)channel * e->buf.coded_stride, in->coded_tail, kTail, hipMemcpyHostToDevice));
+    uint8_t lg[16] = {0};
+    std::memcpy(lg, in->last_group, 12);
+    HIP_TRY(hipMemcpy(e->buf.last_group + (size_t)channel * 16, lg, 16, hipMemcpyHostToDevice));
+    uint32_t cw[4] = {0, 0, 0, 0};
+    for (int en = 0; en < 12; ++en) {
+        const uint32_t b = (in->z2[en] & 1u) | ((in->z0_next[en] & 1u) << 1) | ((in->z0_prev[en] & 1u) << 2);
+        cw[en / 4] |= b << (8 * (en % 4));
+    }
+    HIP_TRY(hipMemcpy(e->buf.carry + channel, cw, 16, hipMemcpyHostToDevice));
+    if (in->field_index != e->field_index) {
+        // T_f = T_0 (x) scale^f by the reference's own sequential fp32 recursion (offset.h:35-41)
+        HIP_TRY(hipMemcpy(e->d_osc[e->osc_cur ^ 1], e->tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice));
+        uint64_t left = in->field_index;
+        int src = e->osc_cur ^ 1;
+        while (left > 0) {
+            const unsigned n = (unsigned)std::min<uint64_t>(left, 1u << 20);
+            launch_osc_advance(nullptr, e->d_osc[src], e->d_osc[src ^ 1], e->scale, n);
+            src ^= 1;
+            left -= n;
+        }
+        HIP_TRY(hipDeviceSynchronize());
+        e->osc_cur = src;
+        e->field_index = in->field_index;
+    }
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_span_parity(atsc_hip_encoder* e, int channel, uint8_t* out36) {
+    if (!e || !out36 || channel < 0 || channel >= e->cfg.channels) return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t cw[4];
+    HIP_TRY(hipMemcpy(cw, e->buf.span_par + channel, 16, hipMemcpyDeviceToHost));
+    for (int en = 0; en < 12; ++en) {
+        const uint32_t b = (cw[en / 4] >> (8 * (en % 4))) & 0xff;
+        out36[en] = b & 1;
+        out36[12 + en] = (b >> 1) & 1;
+        out36[24 + en] = (b >> 2) & 1;
+    }
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_stage_buffer(atsc_hip_encoder* e, int stage, void** d_ptr, size_t* bytes, size_t* channel_stride) {
+    if (!e || !d_ptr) return ATSC_HIP_ERR_ARG;
+    size_t b = 0, st = 0;
+    void* p = nullptr;
+    switch (stage) {
+        case ATSC_HIP_STAGE_RAND_RS: p = e->buf.coded; st = e->buf.coded_stride; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_INTERLEAVE: p = e->buf.il; st = e->buf.il_stride; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_TRELLIS_PAR: p = e->buf.par; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_TRELLIS_SCAN: p = e->buf.cin; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_TRELLIS_MAP: p = e->d_sym; st = (size_t)e->last_fields * kFieldSyms; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_MIX_FIR: p = e->d_osc[e->osc_cur]; st = 0; b = sizeof(float2) * kPaddedSyms; break;
+        default: return ATSC_HIP_ERR_ARG;
+    }
+    *d_ptr = p;
+    if (bytes) *bytes = b;
+    if (channel_stride) *channel_stride = st;
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_last_timings(atsc_hip_encoder* e, float* ms) {
+    if (!e || !ms) return ATSC_HIP_ERR_ARG;
+    if (!e->ev_valid) return ATSC_HIP_ERR_STATE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    for (int i = 0; i < ATSC_HIP_NSTAGES; ++i) ms[i] = 0.f;
+    // each stage runs from its own mark to the next recorded mark
+    int prev = -1;
+    for (int i = 0; i <= ATSC_HIP_NSTAGES; ++i) {
+        if (!e->ev_recorded[i]) continue;
+        if (prev >= 0) {
+            HIP_TRY(hipEventSynchronize(e->ev[i]));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, e->ev[prev], e->ev[i]));
+            ms[prev] = t;
+        }
+        prev = i;
+    }
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_get_table(atsc_hip_encoder* e, int which, void* h_out, size_t bytes) {
+    if (!h_out) return ATSC_HIP_ERR_ARG;
+    // enc == NULL: build the (device-independent) tables on the fly; needs no GPU.
+    atsc_tables::Tables local;
+    const atsc_tables::Tables* t = e ? &e->tab : &local;
+    if (!e) atsc_tables::build(local);
+    const void* src = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case 0: src = t->taps; n = sizeof(float) * kTaps; break;
+        case 1: src = t->osc0.data(); n = sizeof(float) * 2 * kPaddedSyms; break;
+        case 2: src = t->scale; n = sizeof(float) * 2; break;
+        case 3: src = t->prbs.data(); n = t->prbs.size(); break;
+        case 4: src = t->fsync[0].data(); n = 820; break;
+        case 5: src = t->fsync[1].data(); n = 820; break;
+        case 6: src = t->rs_gen; n = 21; break;
+        default: return ATSC_HIP_ERR_ARG;
+    }
+    if (bytes < n) return ATSC_HIP_ERR_ARG;
+    std::memcpy(h_out, src, n);
+    return ATSC_HIP_OK;
+}

@@ -1,0 +1,63 @@
+// Launch interface between the C-ABI host layer (atsc_hip.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace atsc_k {
+
+// Geometry of the path (reference: src/common/atsc_parameters.h:5-25).
+constexpr int kPackets = 312;
+constexpr int kTsBytes = 188;
+constexpr int kSegCoded = 207;
+constexpr int kFieldTs = kPackets * kTsBytes;      // 58656
+constexpr int kFieldCoded = kPackets * kSegCoded;  // 64584
+constexpr int kSegSyms = 832;
+constexpr int kFieldSyms = 313 * kSegSyms;         // 260416
+constexpr int kPaddedSyms = kFieldSyms + kSegSyms; // 261248
+constexpr int kTail = 208 * 51;                    // 10608 coded bytes of history the interleaver needs
+constexpr int kParts = 26;                         // trellis "parts" per field: 12 segments = 207 byte-times each
+constexpr int kPartGroups = 207;                   // 12-byte groups (byte-times) per part
+constexpr int kTaps = 112;
+
+// FIR tiling.
+constexpr int kFirR = 8;                           // consecutive outputs per lane
+constexpr int kFirThreads = 256;
+constexpr int kFirTile = kFirThreads * kFirR;      // 2048 outputs per block iteration
+constexpr int kFirTiles = (kFieldSyms + kFirTile - 1) / kFirTile;  // 128
+constexpr int kFirCols = (kFirTile + 112) / kFirR; // 270 staged columns of 8 samples
+
+struct DeviceTables {
+    const uint32_t* prbs188;   // 58656 B, TS-field layout, dword view
+    const uint4* rs_rows;      // 256 rows x 32 B
+    const uint8_t* fsync;      // 2 x 832 B (even, odd)
+};
+
+struct Buffers {
+    // [channel] strides in bytes
+    uint8_t* coded;  size_t coded_stride;   // per channel: [kTail history | fields*64584]
+    uint8_t* il;     size_t il_stride;      // per channel: fields*64584, transmission order
+    uint4* par;                              // [channel][fields*26] parities (3 words used)
+    uint4* cin;                              // [channel][fields*26] carries entering each part
+    uint4* carry;                            // [channel] trellis state entering the batch (updated by the scan)
+    uint4* span_par;                         // [channel] XOR of all parities of the batch
+    uint8_t* last_group;                     // [channel][16] last 12 interleaved bytes of the previous field
+    int max_fields;
+};
+
+void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
+                    int channels, int fields);
+void launch_interleave(hipStream_t s, const Buffers& b, int channels, int fields);
+void launch_trellis_parity(hipStream_t s, const Buffers& b, int channels, int fields);
+void launch_trellis_scan(hipStream_t s, const Buffers& b, int channels, int fields);
+void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride,
+                        int channels, int fields, uint64_t field_base);
+void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields);
+// Mixer + FIR.  osc_in/osc_out: 261248 complex64 each (double-buffered state); scale = per-field rotation.
+void launch_mix_fir(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride /*complex*/,
+                    const float2* osc_in, float2* osc_out, float2 scale, int channels, int fields);
+void launch_osc_advance(hipStream_t s, const float2* osc_in, float2* osc_out, float2 scale, unsigned steps);
+hipError_t upload_taps(const float* taps112);
+
+}  // namespace atsc_k

@@ -1,0 +1,625 @@
+// gfx950 (MI355X / CDNA4) kernels of the ATSC 8VSB modulator hot path.
+//
+//   k_rand_rs        randomizer (PRBS XOR) + RS(207,187) parity            reference: randomize.h:43-54, reed_solomon.h:192-242
+//   k_interleave     52-branch convolutional byte interleaver as an LDS shear   reference: interleaver.h:11-108
+//   k_trellis_parity per-part GF(2) parities of the 12 precoders/trellis encoders  reference: trellis.h:10-51,240-242
+//   k_trellis_scan   exclusive XOR scan of the parities -> carry entering every part
+//   k_trellis_map    precoder + trellis + 8-level map + segment/field sync -> u8 symbols   reference: trellis.h:121-499,549-576, field_sync.h:12-26
+//   k_mix_fir        pilot/offset mixer + 112-tap RRC FIR -> complex64          reference: offset.h:11-45, filter.h:9-69
+//   k_osc_advance    oscillator table advance by n fields                        reference: offset.h:35-41
+//   k_save_state     end-of-batch history (interleaver tail, last group)
+//
+// All byte/bit stages are bit-exact restatements of the closed forms in SURVEY.md Appendix A; the float
+// stage follows the reference's rounding for the oscillator recursion and sums the FIR in tap order.
+#include "kernels.h"
+
+#include <utility>
+
+namespace atsc_k {
+
+// ======================================================================================= K1 rand + RS
+// One thread owns one packet and runs the systematic LFSR byte-serially; the 20 GF(256) constant
+// multiplies of a step come from ONE 32-byte LDS row indexed by the feedback byte (row[fb] =
+// {g19*fb .. g0*fb}), so a step is 2 LDS reads + a 160-bit byte shift + 5 XORs.  Packets are staged
+// through LDS with coalesced dword loads (PRBS XOR fused into the load) and written back as whole
+// dwords of the 207-byte coded packets.  LDS rows are 53 dwords (odd) so the per-thread row walk is
+// bank-conflict-free.
+constexpr int kRsThreads = 256;
+constexpr int kRsRowDw = 53;
+
+__global__ __launch_bounds__(kRsThreads) void k_rand_rs(const uint8_t* __restrict__ ts, size_t ts_stride,
+                                                        uint8_t* __restrict__ coded, size_t coded_stride,
+                                                        const uint32_t* __restrict__ prbs188,
+                                                        const uint4* __restrict__ rs_rows, int fields) {
+    __shared__ uint32_t s_pkt[kRsThreads * kRsRowDw];  // 54272 B
+    __shared__ uint4 s_rows[512];                      // 8192 B: 256 rows x 2 uint4
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y;
+    const int pkt0 = blockIdx.x * kRsThreads;
+    const int total = fields * kPackets;
+    const int npk = min(kRsThreads, total - pkt0);
+
+    s_rows[tid] = rs_rows[tid];
+    s_rows[tid + 256] = rs_rows[tid + 256];
+
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride + (size_t)pkt0 * kTsBytes);
+    const int ndw = npk * 47;
+    for (int i = tid; i < ndw; i += kRsThreads) {
+        const int q = i / 47;
+        const int w = i - q * 47;
+        const int s = (pkt0 + q) % kPackets;
+        s_pkt[q * kRsRowDw + w] = src[i] ^ prbs188[s * 47 + w];
+    }
+    __syncthreads();
+
+    if (tid < npk) {
+        uint32_t* row = s_pkt + tid * kRsRowDw;
+        const uint32_t* rows32 = reinterpret_cast<const uint32_t*>(s_rows);
+        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+#pragma unroll 1
+        for (int w = 0; w < 47; ++w) {
+            const uint32_t d = row[w];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (w == 0 && j == 0) continue;  // TS sync byte: dropped unchecked (randomize.h:48)
+                const uint32_t fb = ((d >> (8 * j)) ^ b0) & 0xffu;
+                const uint4 r = *reinterpret_cast<const uint4*>(rows32 + fb * 8);
+                const uint32_t r4 = rows32[fb * 8 + 4];
+                b0 = __builtin_amdgcn_alignbyte(b1, b0, 1) ^ r.x;
+                b1 = __builtin_amdgcn_alignbyte(b2, b1, 1) ^ r.y;
+                b2 = __builtin_amdgcn_alignbyte(b3, b2, 1) ^ r.z;
+                b3 = __builtin_amdgcn_alignbyte(b4, b3, 1) ^ r.w;
+                b4 = (b4 >> 8) ^ r4;
+            }
+        }
+        row[47] = b0; row[48] = b1; row[49] = b2; row[50] = b3; row[51] = b4;
+    }
+    __syncthreads();
+
+    // Coded packet q = row bytes 1..207 (187 randomized data bytes, then bb[0..19]).
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_pkt);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(coded + (size_t)c * coded_stride + kTail + (size_t)pkt0 * kSegCoded);
+    const int nout = npk * kSegCoded / 4;  // npk*207 is a multiple of 4 for every block (see launch)
+    for (int i = tid; i < nout; i += kRsThreads) {
+        const int o = 4 * i;
+        const int q0 = o / kSegCoded;
+        const int r0 = o - q0 * kSegCoded;
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + ((r0 + j) >= kSegCoded ? 1 : 0);
+            v |= (uint32_t)s8[o + j + 1 + 5 * q] << (8 * j);  // 212*q + 1 + r with r = o+j-207q
+        }
+        dst[i] = v;
+    }
+}
+
+void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
+                    int channels, int fields) {
+    const int total = fields * kPackets;
+    dim3 grid((total + kRsThreads - 1) / kRsThreads, channels);
+    hipLaunchKernelGGL(k_rand_rs, grid, dim3(kRsThreads), 0, s, d_ts, ts_stride, b.coded, b.coded_stride, t.prbs188,
+                       t.rs_rows, fields);
+}
+
+// ======================================================================================= K2 interleaver
+// The coded stream of a channel viewed as rows of 52 bytes is sheared: IL[a][r] = E[a - 4r][r]
+// (IL[M] = E[M - 208*(M mod 52)], B=52, M=4).  A block produces 621 output rows (half
+// a field) from 825 source rows staged in LDS with coalesced dword loads; each output dword gathers 4
+// bytes that sit 207 bytes apart in LDS (odd dword stride -> conflict-free) and is stored coalesced.
+constexpr int kIlRows = 621;
+constexpr int kIlSrcDw = (kIlRows + 204) * 52 / 4;  // 10725
+constexpr int kIlOutDw = kIlRows * 52 / 4;          // 8073
+
+__global__ __launch_bounds__(256) void k_interleave(const uint8_t* __restrict__ coded, size_t coded_stride,
+                                                    uint8_t* __restrict__ il, size_t il_stride) {
+    __shared__ uint32_t s_src[kIlSrcDw];  // 42900 B
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y;
+    const int h = blockIdx.x;  // half-field index within the batch
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(coded + (size_t)c * coded_stride + (size_t)h * (kIlRows * 52));
+    for (int i = tid; i < kIlSrcDw; i += 256) s_src[i] = src[i];
+    __syncthreads();
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_src);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(il + (size_t)c * il_stride + (size_t)h * (kIlRows * 52));
+    for (int d = tid; d < kIlOutDw; d += 256) {
+        const int a = d / 13;
+        const int r = 4 * (d - 13 * a);
+        const int base = (a + 204 - 4 * r) * 52 + r;
+        const uint32_t v = (uint32_t)s8[base] | ((uint32_t)s8[base - 207] << 8) | ((uint32_t)s8[base - 414] << 16) |
+                           ((uint32_t)s8[base - 621] << 24);
+        dst[d] = v;
+    }
+}
+
+void launch_interleave(hipStream_t s, const Buffers& b, int channels, int fields) {
+    dim3 grid(2 * fields, channels);
+    hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, b.coded, b.coded_stride, b.il, b.il_stride);
+}
+
+// ======================================================================================= trellis helpers
+// A byte-time g (12 interleaved bytes) feeds one byte to each of the 12 encoders.  Encoder e takes
+// IL[12g + ((e - 4*sigma) mod 12)], sigma = floor(12g/207) mod 3, so the three
+// dwords of a group are whole 4-encoder words that only rotate: E_k = D_((k - sigma) mod 3) holds the
+// bytes of encoders 4k..4k+3.  All per-encoder work is done on 4 encoders at once inside a dword.
+//
+// Per byte (4 symbols, MSB pair first; x2 = odd bits, x1 = even bits):
+//   Z2[tau] = c2 ^ x2[0..tau]                       (precoder, inclusive prefix)
+//   Z0[0]=sA, Z0[1]=sB^x1[0], Z0[2]=sA^x1[1], Z0[3]=sB^x1[0]^x1[2]   (Z0[t] = x1[t-1] ^ Z0[t-2])
+// with the carries (c2, sA, sB) entering the byte; after it c2 ^= parity(x2), sA ^= x1[1]^x1[3],
+// sB ^= x1[0]^x1[2].  Carries/parities are packed per encoder byte as bit0=c2, bit1=sA, bit2=sB.
+struct Words3 { uint32_t w[3]; };
+
+__device__ __forceinline__ int sigma_of(int g) { return ((12 * g) / kSegCoded) % 3; }
+
+__device__ __forceinline__ Words3 canonical_group(const uint32_t* p, int g) {
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    const int sg = sigma_of(g);
+    Words3 e;
+    e.w[0] = sg == 0 ? d0 : (sg == 1 ? d2 : d1);
+    e.w[1] = sg == 0 ? d1 : (sg == 1 ? d0 : d2);
+    e.w[2] = sg == 0 ? d2 : (sg == 1 ? d1 : d0);
+    return e;
+}
+
+__device__ __forceinline__ void trellis_local(uint32_t e, uint32_t& z2, uint32_t& z0, uint32_t& par) {
+    uint32_t y = e & 0xAAAAAAAAu;
+    y ^= (y >> 2) & 0x2A2A2A2Au;
+    y ^= (y >> 4) & 0x0A0A0A0Au;
+    z2 = y;
+    const uint32_t u = (e >> 2) & 0x15151515u;
+    z0 = u ^ ((u >> 4) & 0x01010101u);
+    const uint32_t x1 = e & 0x55555555u;
+    const uint32_t p2 = (y >> 1) & 0x01010101u;
+    const uint32_t pa = ((x1 >> 4) ^ x1) & 0x01010101u;
+    const uint32_t pb = ((x1 >> 6) ^ (x1 >> 2)) & 0x01010101u;
+    par = p2 | (pa << 1) | (pb << 2);
+}
+
+__device__ __forceinline__ uint32_t wave_xor_inclusive(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v ^= o;
+    }
+    return v;
+}
+
+// ======================================================================================= K3a parities
+__global__ __launch_bounds__(256) void k_trellis_parity(const uint8_t* __restrict__ il, size_t il_stride,
+                                                        uint4* __restrict__ par, int fields) {
+    __shared__ uint32_t s_red[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = blockIdx.z, f = blockIdx.y, p = blockIdx.x;
+    uint32_t pr[3] = {0, 0, 0};
+    if (tid < kPartGroups) {
+        const int g = p * kPartGroups + tid;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(il + (size_t)c * il_stride + (size_t)f * kFieldCoded) + 3 * g;
+        const Words3 e = canonical_group(src, g);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint32_t z2, z0;
+            trellis_local(e.w[k], z2, z0, pr[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        uint32_t v = pr[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, 64);
+        if (lane == 0) s_red[wv][k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint4 o;
+        o.x = s_red[0][0] ^ s_red[1][0] ^ s_red[2][0] ^ s_red[3][0];
+        o.y = s_red[0][1] ^ s_red[1][1] ^ s_red[2][1] ^ s_red[3][1];
+        o.z = s_red[0][2] ^ s_red[1][2] ^ s_red[2][2] ^ s_red[3][2];
+        o.w = 0;
+        par[((size_t)c * fields + f) * kParts + p] = o;
+    }
+}
+
+void launch_trellis_parity(hipStream_t s, const Buffers& b, int channels, int fields) {
+    dim3 grid(kParts, fields, channels);
+    hipLaunchKernelGGL(k_trellis_parity, grid, dim3(256), 0, s, b.il, b.il_stride, b.par, fields);
+}
+
+// ======================================================================================= K3 scan
+// One wave per channel: exclusive XOR scan over fields*26 parts, seeded with the channel's carry.
+// Lane l owns one field (26 parts) per pass of 64 fields.
+__global__ __launch_bounds__(64) void k_trellis_scan(const uint4* __restrict__ par, uint4* __restrict__ cin,
+                                                     uint4* __restrict__ carry, uint4* __restrict__ span_par, int fields) {
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x;
+    const uint4 init = carry[c];
+    uint32_t run[3] = {init.x, init.y, init.z};
+    for (int f0 = 0; f0 < fields; f0 += 64) {
+        const int f = f0 + lane;
+        const bool on = f < fields;
+        const uint4* pp = par + ((size_t)c * fields + (on ? f : 0)) * kParts;
+        uint32_t tot[3] = {0, 0, 0};
+        if (on) {
+            for (int p = 0; p < kParts; ++p) {
+                const uint4 v = pp[p];
+                tot[0] ^= v.x; tot[1] ^= v.y; tot[2] ^= v.z;
+            }
+        }
+        uint32_t pre[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t inc = wave_xor_inclusive(tot[k], lane);
+            pre[k] = run[k] ^ inc ^ tot[k];  // exclusive prefix for this lane's field
+            run[k] ^= __shfl(inc, 63, 64);   // all lanes: total of this pass
+        }
+        if (on) {
+            uint4* co = cin + ((size_t)c * fields + f) * kParts;
+            for (int p = 0; p < kParts; ++p) {
+                co[p] = make_uint4(pre[0], pre[1], pre[2], 0);
+                const uint4 v = pp[p];
+                pre[0] ^= v.x; pre[1] ^= v.y; pre[2] ^= v.z;
+            }
+        }
+    }
+    if (lane == 0) {
+        carry[c] = make_uint4(run[0], run[1], run[2], 0);
+        span_par[c] = make_uint4(run[0] ^ init.x, run[1] ^ init.y, run[2] ^ init.z, 0);
+    }
+}
+
+void launch_trellis_scan(hipStream_t s, const Buffers& b, int channels, int fields) {
+    hipLaunchKernelGGL(k_trellis_scan, dim3(channels), dim3(64), 0, s, b.par, b.cin, b.carry, b.span_par, fields);
+}
+
+// ======================================================================================= K4 map + sync
+// Block = one part (12 data segments, 207 byte-times) of one field of one channel.  Lane = byte-time:
+// local prefix inside the byte, wave/block XOR scan of the byte parities for the carries, then the
+// 4 symbol-times x 12 encoders = 48 symbols of the lane go to an LDS image of the 12 output segments
+// (data symbol j of segment s = encoder (4s+j) mod 12, symbol t = 69s + j/12), segment syncs are
+// added, and the image is stored with coalesced 16-byte writes.  Part 0 also writes the field-sync
+// segment, whose last 12 symbols repeat the previous field's last 12 data symbols: those are
+// 4*c2 + 2*x1_last + sB of each encoder at the field boundary, all known from the carries and the
+// previous field's last interleaved group.
+__global__ __launch_bounds__(256) void k_trellis_map(const uint8_t* __restrict__ il, size_t il_stride,
+                                                     const uint4* __restrict__ cin, const uint8_t* __restrict__ last_group,
+                                                     const uint8_t* __restrict__ fsync, uint8_t* __restrict__ sym,
+                                                     size_t sym_stride, int fields, unsigned parity0) {
+    __shared__ uint32_t s_img[12 * kSegSyms / 4];  // 9984 B
+    __shared__ uint32_t s_wtot[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = blockIdx.z, f = blockIdx.y, p = blockIdx.x;
+    const uint8_t* il_f = il + (size_t)c * il_stride + (size_t)f * kFieldCoded;
+    const uint4 ci = cin[((size_t)c * fields + f) * kParts + p];
+    const uint32_t cinw[3] = {ci.x, ci.y, ci.z};
+
+    uint32_t ew[3] = {0, 0, 0}, z2[3], z0[3], pr[3] = {0, 0, 0};
+    const int g = p * kPartGroups + tid;
+    if (tid < kPartGroups) {
+        const Words3 e = canonical_group(reinterpret_cast<const uint32_t*>(il_f) + 3 * g, g);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ew[k] = e.w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) trellis_local(ew[k], z2[k], z0[k], pr[k]);
+
+    uint32_t inc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        inc[k] = wave_xor_inclusive(pr[k], lane);
+        if (lane == 63) s_wtot[wv][k] = inc[k];
+    }
+    if (tid < 12) {  // segment syncs 6,1,1,6 of the 12 segments
+        s_img[tid * (kSegSyms / 4)] = 0x06010106u;
+    }
+    __syncthreads();
+
+    if (tid < kPartGroups) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            uint32_t cw = cinw[k] ^ inc[k] ^ pr[k];
+            for (int w = 0; w < wv; ++w) cw ^= s_wtot[w][k];
+            const uint32_t zz2 = z2[k] ^ ((cw & 0x01010101u) * 0xAAu);
+            const uint32_t zz0 = z0[k] ^ (((cw >> 1) & 0x01010101u) * 0x44u) ^ (((cw >> 2) & 0x01010101u) * 0x11u);
+            const uint32_t hi = zz2 | (ew[k] & 0x55555555u);
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) {
+                const int sh = 6 - 2 * tau;
+                const uint32_t v = (((hi >> sh) & 0x03030303u) << 1) | ((zz0 >> sh) & 0x01010101u);
+                const int t = 4 * tid + tau;     // symbol time inside the part (0..827)
+                const int sl = t / 69;           // local segment 0..11 (field segment 12p+sl, and 12p = 0 mod 3)
+                const int q = t - 69 * sl;
+                const int hslot = (k + 3 - sl % 3) % 3;
+                s_img[sl * (kSegSyms / 4) + 1 + 3 * q + hslot] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    uint8_t* out_f = sym + (size_t)c * sym_stride + (size_t)f * kFieldSyms;
+    {
+        const uint4* img4 = reinterpret_cast<const uint4*>(s_img);
+        uint4* dst = reinterpret_cast<uint4*>(out_f + (size_t)(1 + 12 * p) * kSegSyms);
+        for (int i = tid; i < 12 * kSegSyms / 16; i += 256) dst[i] = img4[i];
+    }
+    if (p == 0 && tid < kSegSyms / 16) {
+        // field sync segment; parity of the absolute field index selects the middle PN63 polarity
+        const uint4* fs = reinterpret_cast<const uint4*>(fsync + (((parity0 + (unsigned)f) & 1u) ? kSegSyms : 0));
+        uint4 v = fs[tid];
+        if (tid == 51) {
+            // bytes 816..831: 816..819 come from the table, 820..831 are the reserved symbols
+            const uint32_t* lg = (f == 0) ? reinterpret_cast<const uint32_t*>(last_group + (size_t)c * 16)
+                                          : reinterpret_cast<const uint32_t*>(il_f - 12);
+            const int gl = kFieldCoded / 12 - 1;  // last byte-time of the previous field
+            const Words3 pe = canonical_group(lg, gl);
+            uint32_t rs[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t w = ((cinw[k] & 0x01010101u) << 2) | ((pe.w[k] & 0x01010101u) << 1) |
+                                   ((cinw[k] >> 2) & 0x01010101u);
+                rs[(k + 1) % 3] = w;  // segment 311: slot h holds encoder group (h + 311) mod 3 = (h + 2) mod 3
+            }
+            v.y = rs[0]; v.z = rs[1]; v.w = rs[2];
+        }
+        reinterpret_cast<uint4*>(out_f)[tid] = v;
+    }
+}
+
+void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride,
+                        int channels, int fields, uint64_t field_base) {
+    dim3 grid(kParts, fields, channels);
+    hipLaunchKernelGGL(k_trellis_map, grid, dim3(256), 0, s, b.il, b.il_stride, b.cin, b.last_group, t.fsync, d_sym,
+                       sym_stride, fields, (unsigned)(field_base & 1));
+}
+
+// ======================================================================================= K7 state save
+__global__ __launch_bounds__(256) void k_save_state(uint8_t* __restrict__ coded, size_t coded_stride,
+                                                    const uint8_t* __restrict__ il, size_t il_stride,
+                                                    uint8_t* __restrict__ last_group, int fields) {
+    const int c = blockIdx.x;
+    uint32_t* base = reinterpret_cast<uint32_t*>(coded + (size_t)c * coded_stride);
+    const uint32_t* tail = base + (size_t)fields * (kFieldCoded / 4);
+    for (int i = threadIdx.x; i < kTail / 4; i += 256) base[i] = tail[i];  // fields*64584 >= 10608: no overlap
+    if (threadIdx.x < 3) {
+        const uint32_t* lg = reinterpret_cast<const uint32_t*>(il + (size_t)c * il_stride + (size_t)fields * kFieldCoded - 12);
+        reinterpret_cast<uint32_t*>(last_group + (size_t)c * 16)[threadIdx.x] = lg[threadIdx.x];
+    }
+}
+
+void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields) {
+    hipLaunchKernelGGL(k_save_state, dim3(channels), dim3(256), 0, s, b.coded, b.coded_stride, b.il, b.il_stride,
+                       b.last_group, fields);
+}
+
+// ======================================================================================= K5 mixer + FIR
+// y[i] = sum_k c[k] * x[i+k] * T_f[i+k], x = 2v - 7 + 1.25 real, T_f complex (offset.h, filter.h).
+// VALU-bound (446 flop/sample): each lane keeps kFirR consecutive complex outputs in registers and
+// slides over kFirR+110 staged samples, one ds_read_b64 per sample and up to kFirR packed FMAs
+// (v_pk_fma_f32: re,im in one instruction, tap broadcast from an SGPR).  Staged samples live in LDS
+// transposed by (sample mod 8) so that both the staging writes and the sliding reads are
+// conflict-free.  The oscillator slice of the tile stays in registers for the whole kernel: a block
+// walks fields f_lo..f_hi of its channels and advances its slice by the reference's fp32 recursion
+// (re = fma(cr,er,-(ci*ei)), im = fma(ci,er,cr*ei)) once per field, so no per-field table is ever
+// written to HBM.  Symbols of the next (channel, field) are prefetched into registers while the
+// current tile is being filtered.
+// The 111 taps are symmetric (c[k] == c[110-k] bit-for-bit, checked on the host) and c[111] == 0, so the
+// 56 unique values live in 28 aligned SGPR pairs for the whole kernel; op_sel picks the half of a pair
+// that is broadcast to both lanes of the packed FMA.
+__constant__ unsigned long long c_tap_pairs[28];
+
+hipError_t upload_taps(const float* taps112) {
+    float pairs[56];
+    for (int k = 0; k < 56; ++k) pairs[k] = taps112[k];
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_tap_pairs), pairs, sizeof pairs);
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// acc += x * c[k] on (re, im) at once.  k is a compile-time constant after unrolling.
+__device__ __forceinline__ void fir_fma(v2f& acc, const v2f x, const unsigned long long (&tp)[28], const int k) {
+    const int u = k <= 55 ? k : 110 - k;
+    if (u & 1)
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(tp[u >> 1]));
+    else
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(tp[u >> 1]));
+}
+
+__device__ __forceinline__ float2 osc_step(float2 t, float2 sc) {
+    const float t2 = __fmul_rn(t.y, sc.y);
+    const float t3 = __fmul_rn(t.x, sc.y);
+    return make_float2(__fmaf_rn(t.x, sc.x, -t2), __fmaf_rn(t.y, sc.x, t3));
+}
+
+struct SymRegs { uint32_t lo, hi; bool on; };
+
+// Symbols for 8 consecutive padded positions starting at pos (multiple of 8):
+// pos < 260416: the field; 260416 <= pos < 260416+112: copy of the field's sync head (field_sync.h:16);
+// beyond: never reaches a valid output (c[111] = 0), treated as 0.
+__device__ __forceinline__ SymRegs load_syms(const uint8_t* sym_f, int pos) {
+    SymRegs r{0u, 0u, false};
+    int src = -1;
+    if (pos < kFieldSyms) src = pos;
+    else if (pos < kFieldSyms + 112) src = pos - kFieldSyms;
+    if (src >= 0) {
+        const uint2 v = *reinterpret_cast<const uint2*>(sym_f + src);
+        r.lo = v.x; r.hi = v.y; r.on = true;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float level_of(uint32_t w, int j) {
+    // 2v - 7 + 1.25 (signal.h:16): exact in fp32
+    return __fmaf_rn((float)((w >> (8 * j)) & 0xffu), 2.0f, -5.75f);
+}
+
+// 8 oscillator entries starting at pos (multiple of 8; the table length is a multiple of 8)
+__device__ __forceinline__ void load_osc8(const float2* osc, int pos, bool on, float2 (&t)[kFirR]) {
+    if (on && pos < kPaddedSyms) {
+        const float4* p = reinterpret_cast<const float4*>(osc + pos);
+#pragma unroll
+        for (int j = 0; j < kFirR / 2; ++j) {
+            const float4 v = p[j];
+            t[2 * j] = make_float2(v.x, v.y);
+            t[2 * j + 1] = make_float2(v.z, v.w);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kFirR; ++j) t[j] = make_float2(0.f, 0.f);
+    }
+}
+
+constexpr int kFirDepth = 6;  // LDS reads in flight ahead of the FMAs that consume them
+constexpr int kFirSteps = kFirR + 110;
+
+// One step of the sliding window, fully resolved at compile time: sample J (already in the ring)
+// feeds the outputs r with tap k = J - r in 0..110, and the read of sample J + depth is issued.
+template <int J>
+__device__ __forceinline__ void fir_step(v2f (&acc)[kFirR], v2f (&ring)[kFirDepth], const v2f* xs,
+                                         const unsigned long long (&tp)[28]) {
+    const v2f x = ring[J % kFirDepth];
+    if constexpr (J + kFirDepth < kFirSteps) {
+        constexpr int jn = J + kFirDepth;
+        ring[J % kFirDepth] = xs[(jn % kFirR) * kFirCols + jn / kFirR];
+    }
+#pragma unroll
+    for (int r = 0; r < kFirR; ++r) {
+        const int k = J - r;
+        if (k >= 0 && k <= 110) fir_fma(acc[r], x, tp, k);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int... Js>
+__device__ __forceinline__ void fir_steps(v2f (&acc)[kFirR], v2f (&ring)[kFirDepth], const v2f* xs,
+                                          const unsigned long long (&tp)[28], std::integer_sequence<int, Js...>) {
+    (fir_step<Js>(acc, ring, xs, tp), ...);
+}
+template <int... Js>
+__device__ __forceinline__ void fir_prime(v2f (&ring)[kFirDepth], const v2f* xs, std::integer_sequence<int, Js...>) {
+    ((ring[Js] = xs[(Js % kFirR) * kFirCols + Js / kFirR]), ...);
+}
+
+__global__ __launch_bounds__(kFirThreads) void k_mix_fir(const uint8_t* __restrict__ sym, size_t sym_stride,
+                                                         float2* __restrict__ iq, size_t iq_stride,
+                                                         const float2* __restrict__ osc_in, float2* __restrict__ osc_out,
+                                                         float2 scale, int channels, int fields, int ch_per_group,
+                                                         int f_per_group) {
+    __shared__ float2 s_x[kFirR * kFirCols];  // 17280 B
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tile = blockIdx.x;
+    const int c_lo = blockIdx.y * ch_per_group, c_hi = min(channels, c_lo + ch_per_group);
+    const int f_lo = blockIdx.z * f_per_group, f_hi = min(fields, f_lo + f_per_group);
+    const bool halo = tid < (kFirCols - kFirThreads);  // threads 0..13 also stage the 112-sample look-ahead
+    const int pos_main = tile * kFirTile + kFirR * tid;
+    const int pos_halo = (tile + 1) * kFirTile + kFirR * tid;
+
+    unsigned long long tp[28];
+#pragma unroll
+    for (int m = 0; m < 28; ++m) tp[m] = c_tap_pairs[m];
+
+    // oscillator slice -> registers, advanced to field f_lo
+    float2 tm[kFirR], th[kFirR];
+    load_osc8(osc_in, pos_main, true, tm);
+    load_osc8(osc_in, pos_halo, halo, th);
+    for (int n = 0; n < f_lo; ++n) {
+#pragma unroll
+        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
+    }
+
+    const int out0 = tile * kFirTile + wv * (64 * kFirR) + lane * kFirR;  // first output of this lane
+    const bool lane_on = out0 < kFieldSyms;                                 // 260416 - 127*2048 = 320 = 8*40
+
+    SymRegs sm, sh;
+    {
+        const uint8_t* sf = sym + (size_t)c_lo * sym_stride + (size_t)f_lo * kFieldSyms;
+        sm = load_syms(sf, pos_main);
+        sh = halo ? load_syms(sf, pos_halo) : SymRegs{0u, 0u, false};
+    }
+
+    for (int f = f_lo; f < f_hi; ++f) {
+        for (int c = c_lo; c < c_hi; ++c) {
+            // ---- stage current symbols x oscillator into LDS (transposed by sample mod 8)
+#pragma unroll
+            for (int j = 0; j < kFirR; ++j) {
+                const float x = sm.on ? level_of(j < 4 ? sm.lo : sm.hi, j & 3) : 0.0f;
+                s_x[j * kFirCols + tid] = make_float2(__fmul_rn(x, tm[j].x), __fmul_rn(x, tm[j].y));
+            }
+            if (halo) {
+#pragma unroll
+                for (int j = 0; j < kFirR; ++j) {
+                    const float x = sh.on ? level_of(j < 4 ? sh.lo : sh.hi, j & 3) : 0.0f;
+                    s_x[j * kFirCols + kFirThreads + tid] = make_float2(__fmul_rn(x, th[j].x), __fmul_rn(x, th[j].y));
+                }
+            }
+            __syncthreads();
+
+            // ---- prefetch the next (channel, field) symbols
+            {
+                int cn = c + 1, fn = f;
+                if (cn == c_hi) { cn = c_lo; fn = f + 1; }
+                if (fn < f_hi) {
+                    const uint8_t* sf = sym + (size_t)cn * sym_stride + (size_t)fn * kFieldSyms;
+                    sm = load_syms(sf, pos_main);
+                    if (halo) sh = load_syms(sf, pos_halo);
+                }
+            }
+
+            // ---- sliding-window FIR: sample j feeds outputs r = j-k; kFirDepth LDS reads stay in flight
+            v2f acc[kFirR];
+#pragma unroll
+            for (int r = 0; r < kFirR; ++r) acc[r] = (v2f){0.f, 0.f};
+            const v2f* xs = reinterpret_cast<const v2f*>(s_x) + wv * 64 + lane;
+            v2f ring[kFirDepth];
+            fir_prime(ring, xs, std::make_integer_sequence<int, kFirDepth>{});
+            __builtin_amdgcn_sched_barrier(0);
+            fir_steps(acc, ring, xs, tp, std::make_integer_sequence<int, kFirR + 110>{});
+            if (lane_on) {
+                float4* dst = reinterpret_cast<float4*>(iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + out0);
+#pragma unroll
+                for (int r = 0; r < kFirR; r += 2) dst[r / 2] = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
+            }
+            __syncthreads();
+        }
+        // ---- oscillator advance to the next field (offset.h:35-41)
+#pragma unroll
+        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
+    }
+
+    // The block that handled the last fields of channel group 0 publishes the advanced oscillator slice.
+    if (blockIdx.y == 0 && f_hi == fields && pos_main < kPaddedSyms) {
+        float4* p = reinterpret_cast<float4*>(osc_out + pos_main);
+#pragma unroll
+        for (int j = 0; j < kFirR / 2; ++j) p[j] = make_float4(tm[2 * j].x, tm[2 * j].y, tm[2 * j + 1].x, tm[2 * j + 1].y);
+    }
+}
+
+void launch_mix_fir(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
+                    const float2* osc_in, float2* osc_out, float2 scale, int channels, int fields) {
+    // Decomposition: 128 tiles x channel groups x field groups, aiming at >= ~2048 blocks (8 per CU).
+    const int target = 2048 / kFirTiles;  // 16 (channel group, field group) pairs
+    int ngroups_c = channels < target ? channels : target;
+    int ch_per_group = (channels + ngroups_c - 1) / ngroups_c;
+    ngroups_c = (channels + ch_per_group - 1) / ch_per_group;
+    int ngroups_f = target / ngroups_c;
+    if (ngroups_f < 1) ngroups_f = 1;
+    if (ngroups_f > fields) ngroups_f = fields;
+    int f_per_group = (fields + ngroups_f - 1) / ngroups_f;
+    ngroups_f = (fields + f_per_group - 1) / f_per_group;
+    dim3 grid(kFirTiles, ngroups_c, ngroups_f);
+    hipLaunchKernelGGL(k_mix_fir, grid, dim3(kFirThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_in, osc_out,
+                       scale, channels, fields, ch_per_group, f_per_group);
+}
+
+// ======================================================================================= K6 oscillator advance
+__global__ __launch_bounds__(256) void k_osc_advance(const float2* __restrict__ in, float2* __restrict__ out,
+                                                     float2 scale, unsigned steps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kPaddedSyms) return;
+    float2 t = in[i];
+    for (unsigned n = 0; n < steps; ++n) t = osc_step(t, scale);
+    out[i] = t;
+}
+
+void launch_osc_advance(hipStream_t s, const float2* osc_in, float2* osc_out, float2 scale, unsigned steps) {
+    hipLaunchKernelGGL(k_osc_advance, dim3((kPaddedSyms + 255) / 256), dim3(256), 0, s, osc_in, osc_out, scale, steps);
+}
+
+}  // namespace atsc_k

@@ -1,0 +1,152 @@
+// Constant tables of the 8VSB modulator path (host side).  Each generator cites the reference
+// behaviour it must reproduce bit-for-bit; tests/test_tables.py checks them against the oracle
+// and the golden fixtures.
+#include "tables.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace atsc_tables {
+
+namespace {
+
+// ---- randomizer PRBS (reference: src/atsc/randomize.h:13-33).  16-bit register seeded 0xf180,
+// feedback 0x9c65 applied after the shift; eight fixed register bits form the output byte.
+void build_prbs(Tables& t) {
+    t.prbs.resize(kSegData * kPackets);
+    t.prbs188.assign(kFieldTs, 0);
+    uint32_t reg = 0xf180;
+    for (int s = 0; s < kPackets; ++s) {
+        for (int k = 0; k < kSegData; ++k) {
+            const uint8_t out = static_cast<uint8_t>(((reg >> 6) & 0xf0) | ((reg >> 3) & 0x08) | ((reg >> 1) & 0x06) | (reg & 1));
+            t.prbs[s * kSegData + k] = out;
+            t.prbs188[s * kTsBytes + 1 + k] = out;
+            reg <<= 1;
+            if (reg & 0x10000) reg ^= 0x138cb;  // (0x9c65 << 1) | 1, also clears bit 16
+        }
+    }
+}
+
+// ---- GF(256)/0x11d and the RS(207,187) generator, roots alpha^0..alpha^19
+// (reference: src/atsc/galois.h:85-113, src/atsc/reed_solomon.h:23-39).
+struct Gf {
+    uint8_t exp[510];
+    uint8_t log[256];
+    Gf() {
+        unsigned v = 1;
+        for (int i = 0; i < 255; ++i) {
+            exp[i] = exp[i + 255] = static_cast<uint8_t>(v);
+            log[v] = static_cast<uint8_t>(i);
+            v = (v << 1) ^ ((v & 0x80) ? 0x11d : 0);
+        }
+        log[0] = 0;
+    }
+    uint8_t mul(uint8_t a, uint8_t b) const { return (a && b) ? exp[log[a] + log[b]] : 0; }
+};
+
+void build_rs(Tables& t) {
+    Gf gf;
+    uint8_t g[kParity + 1] = {1};
+    for (int i = 0; i < kParity; ++i) {
+        const uint8_t root = gf.exp[i];
+        for (int j = i + 1; j >= 1; --j) g[j] = g[j - 1] ^ gf.mul(g[j], root);
+        g[0] = gf.mul(g[0], root);
+    }
+    std::memcpy(t.rs_gen, g, sizeof g);
+    // Feedback rows for the systematic LFSR (reference: reed_solomon.h:192-209): after the shift,
+    // parity byte i receives g[19-i]*fb.
+    t.rs_rows.assign(256 * 32, 0);
+    for (int fb = 0; fb < 256; ++fb)
+        for (int i = 0; i < kParity; ++i) t.rs_rows[fb * 32 + i] = gf.mul(g[kParity - 1 - i], static_cast<uint8_t>(fb));
+}
+
+// ---- PN511 / PN63 and the field sync segment (reference: src/common/lfsr.h:10-26,
+// src/atsc/field_sync.h:42-70,81-82).
+std::vector<uint8_t> pn_sequence(unsigned state, unsigned out_bit, unsigned fb_mask, int n) {
+    std::vector<uint8_t> bits(n);
+    for (int i = 0; i < n; ++i) {
+        bits[i] = (state >> out_bit) & 1u;
+        state = (state << 1) | static_cast<unsigned>(__builtin_popcount(state & fb_mask) & 1);
+    }
+    return bits;
+}
+
+void build_fsync(Tables& t) {
+    const auto pn511 = pn_sequence(0b10, 8, 0b110110110, 511);
+    const auto pn63 = pn_sequence(0b111001, 5, 0b110000, 63);
+    const char* vsb_mode = "000010100101111101011010";
+    for (int odd = 0; odd < 2; ++odd) {
+        auto& seg = t.fsync[odd];
+        seg.assign(kSegSyms, 0);
+        int n = 0;
+        auto put = [&](int bit) { seg[n++] = bit ? 6 : 1; };
+        put(1); put(0); put(0); put(1);
+        for (uint8_t b : pn511) put(b);
+        for (uint8_t b : pn63) put(b);
+        for (uint8_t b : pn63) put(odd ? !b : b);  // middle PN63 inverted on odd fields
+        for (uint8_t b : pn63) put(b);
+        for (int i = 0; i < 24; ++i) put(vsb_mode[i] == '1');
+        for (int i = 0; i < 92; ++i) put(pn63[i % 63]);
+        // n == 820; the last 12 symbols are filled per field from the previous field.
+    }
+}
+
+// ---- RRC taps.  The reference hard-codes them (src/atsc/filter.h:71); they are the classic
+// firdes root-raised-cosine (gain 0.1, 2 samples per "symbol", alpha 0.1152, 111 taps) evaluated
+// in double and rounded to float, plus a zero 112th tap.
+void build_taps(Tables& t) {
+    const double alpha = 0.1152, gain = 0.1, spb = 2.0;
+    const int n = 111;
+    float raw[n];
+    double total = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double xi = i - n / 2;
+        const double x1 = M_PI * xi / spb;
+        double x2 = 4 * alpha * xi / spb;
+        double x3 = x2 * x2 - 1;
+        double num, den;
+        if (std::fabs(x3) >= 0.000001) {
+            num = (i != n / 2) ? std::cos((1 + alpha) * x1) + std::sin((1 - alpha) * x1) / (4 * alpha * xi / spb)
+                               : std::cos((1 + alpha) * x1) + (1 - alpha) * M_PI / (4 * alpha);
+            den = x3 * M_PI;
+        } else {
+            x3 = (1 - alpha) * x1;
+            x2 = (1 + alpha) * x1;
+            num = std::sin(x2) * (1 + alpha) * M_PI - std::cos(x3) * ((1 - alpha) * M_PI * spb) / (4 * alpha * xi) +
+                  std::sin(x3) * spb * spb / (4 * alpha * xi * xi);
+            den = -32 * M_PI * alpha * alpha * xi / spb;
+        }
+        raw[i] = static_cast<float>(4 * alpha * num / den);
+        total += raw[i];
+    }
+    for (int i = 0; i < n; ++i) t.taps[i] = static_cast<float>(raw[i] * gain / total);
+    t.taps[111] = 0.0f;
+}
+
+// ---- oscillator (reference: src/atsc/offset.h:84-106).  NOT an ideal NCO: the phase is computed
+// in double but rounded to float before cosf/sinf, and the per-field advance is a float complex.
+void build_osc(Tables& t) {
+    const double fs = 4500000.0 / 286 * 684;
+    const double step = 2 * M_PI * (309411.0 - 3000000.0) / fs;
+    t.osc0.resize(static_cast<size_t>(kPaddedSyms) * 2);
+    for (size_t i = 0; i < static_cast<size_t>(kPaddedSyms); ++i) {
+        const float phase = static_cast<float>(step * i);
+        t.osc0[2 * i] = static_cast<float>(0.9 * cosf(phase));
+        t.osc0[2 * i + 1] = static_cast<float>(0.9 * sinf(phase));
+    }
+    const float phase = static_cast<float>(step * kFieldSyms);
+    t.scale[0] = cosf(phase);
+    t.scale[1] = sinf(phase);
+}
+
+}  // namespace
+
+void build(Tables& t) {
+    build_prbs(t);
+    build_rs(t);
+    build_fsync(t);
+    build_taps(t);
+    build_osc(t);
+}
+
+}  // namespace atsc_tables

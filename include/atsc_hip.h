@@ -1,0 +1,143 @@
+/*
+ * atsc_hip.h -- C-ABI of the MI355X-native ATSC 8VSB modulator hot path.
+ *
+ * This is the drop-in boundary for the encoder library of philburr/atsc
+ * (reference: src/atsc/atsc.h:7-16 -- class atsc::atsc_encoder { create(); process(pkt,count,fn); }).
+ * Everything behind these entry points runs as hand-written HIP kernels for gfx950; there is no
+ * CPU fallback: every call fails with ATSC_HIP_ERR_NO_DEVICE / a HIP error when no GPU is present.
+ *
+ * Plain C types only: pointers, sizes, ints.  `stream` arguments are hipStream_t passed as void*
+ * (NULL = the default stream).  Device pointers are marked d_*, host pointers h_*.
+ *
+ * A handle ("encoder") owns `channels` independent TS streams that advance in lockstep, one field
+ * index for all of them (they share one oscillator table, reference: src/atsc/offset.h:9,81).
+ * Like the reference a handle is NOT thread-safe; handles are independent.
+ */
+#ifndef ATSC_HIP_H
+#define ATSC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Sizes of the path (reference: src/common/atsc_parameters.h:5-25). */
+#define ATSC_HIP_TS_PACKET_BYTES 188
+#define ATSC_HIP_PACKETS_PER_FIELD 312
+#define ATSC_HIP_FIELD_TS_BYTES (312 * 188)      /* 58656   */
+#define ATSC_HIP_FIELD_CODED_BYTES (312 * 207)   /* 64584   */
+#define ATSC_HIP_FIELD_SYMBOLS (313 * 832)       /* 260416  */
+#define ATSC_HIP_FIELD_IQ_BYTES (313 * 832 * 8)  /* 2083328 */
+#define ATSC_HIP_PADDED_SYMBOLS (314 * 832)      /* 261248: oscillator table length, offset.h:9 */
+#define ATSC_HIP_INTERLEAVER_TAIL 10608          /* 208*51 coded bytes carried across a field boundary */
+
+/* Return codes: 0 ok; >0 a hipError_t value; <0 the codes below. */
+#define ATSC_HIP_OK 0
+#define ATSC_HIP_ERR_ARG (-1)
+#define ATSC_HIP_ERR_NO_DEVICE (-2)
+#define ATSC_HIP_ERR_TOO_LARGE (-3)
+#define ATSC_HIP_ERR_STATE (-4)
+
+typedef struct atsc_hip_encoder atsc_hip_encoder;
+
+typedef struct atsc_hip_config {
+    int device;      /* HIP device ordinal */
+    int channels;    /* independent TS streams encoded in lockstep (>=1) */
+    int max_fields;  /* largest number of fields per channel in one batch (>=1) */
+    int flags;       /* ATSC_HIP_FLAG_* */
+} atsc_hip_config;
+
+#define ATSC_HIP_FLAG_TIMING 1 /* record HIP events around every kernel of a batch (atsc_hip_last_timings) */
+
+/* Stage ids for atsc_hip_stage_buffer / atsc_hip_last_timings. */
+enum {
+    ATSC_HIP_STAGE_RAND_RS = 0,   /* randomizer + RS(207,187)            -> coded bytes   */
+    ATSC_HIP_STAGE_INTERLEAVE,    /* convolutional byte interleaver      -> interleaved   */
+    ATSC_HIP_STAGE_TRELLIS_PAR,   /* per-part precoder/trellis parities                   */
+    ATSC_HIP_STAGE_TRELLIS_SCAN,  /* exclusive XOR scan of the parities  -> carries       */
+    ATSC_HIP_STAGE_TRELLIS_MAP,   /* trellis + 8-level map + sync insert -> u8 symbols    */
+    ATSC_HIP_STAGE_MIX_FIR,       /* pilot/offset mixer + RRC FIR        -> complex64 IQ  */
+    ATSC_HIP_STAGE_STATE,         /* end-of-batch state save                               */
+    ATSC_HIP_NSTAGES
+};
+
+/* Per-field completion callback of the streaming path.  Replaces the reference's
+ * std::function<void(void*,unsigned)> (src/atsc/atsc.h:11): same arguments plus a user pointer.
+ * `iq` is library-owned pinned host memory, valid only during the callback (atsc.cpp:89). */
+typedef void (*atsc_hip_field_cb)(void* user, void* iq, unsigned bytes);
+
+/* Replaces atsc::atsc_encoder::create() (src/atsc/atsc.cpp:93-95).  Allocates all device buffers
+ * for channels x max_fields, builds the constant tables, zero history (atsc.cpp:17-35). */
+int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** out);
+
+/* Replaces ~atsc_encoder (src/atsc/atsc.h:9). */
+void atsc_hip_destroy(atsc_hip_encoder* enc);
+
+/* Replaces atsc::atsc_encoder::process (src/atsc/atsc.cpp:59-77) for a 1-channel handle:
+ * `count` contiguous 188-byte TS packets (host memory, copied before return); every completed
+ * 312-packet field fires cb(user, iq, 2083328) synchronously, in order, before the call returns.
+ * All complete fields available are encoded in GPU batches of up to max_fields.  A trailing partial
+ * field stays buffered (no flush API, like the reference). */
+int atsc_hip_process(atsc_hip_encoder* enc, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb, void* user);
+
+/* Batched multi-channel path behind process_field (src/atsc/atsc.cpp:79-90), device-resident.
+ *   d_ts  : [channels][fields][312][188] u8 TS packets
+ *   d_sym : [channels][fields][260416]  u8 level indices 0..7 (symbol tap after field_sync,
+ *           atsc.cpp:84), or NULL to use the library's internal symbol buffer
+ *   d_iq  : [channels][fields][260416]  complex64 (re,im fp32) baseband (atsc.cpp:86,89), or NULL
+ *           to stop after the symbols (the oscillator still advances `fields` fields)
+ * Asynchronous on `stream`; 1 <= fields <= max_fields. */
+int atsc_hip_encode_batch(atsc_hip_encoder* enc, const uint8_t* d_ts, int fields, uint8_t* d_sym, void* d_iq,
+                          void* stream);
+
+/* Same, from/to host memory (pageable or pinned); synchronous.  h_sym / h_iq may be NULL. */
+int atsc_hip_encode_batch_host(atsc_hip_encoder* enc, const uint8_t* h_ts, int fields, uint8_t* h_sym, void* h_iq);
+
+/* Mixer + FIR alone on caller-supplied symbols (reference: offset.process_field + filter.process_field,
+ * src/atsc/atsc.cpp:85-86).  Advances the oscillator by `fields`. */
+int atsc_hip_mix_fir(atsc_hip_encoder* enc, const uint8_t* d_sym, int fields, void* d_iq, void* stream);
+
+/* Stream state at a field boundary: everything field f+1 needs from the past.
+ * Reference counterparts: interleaver next_field contents (atsc.cpp:53-54,82,88), trellis carries
+ * (trellis.h:500-502), saved_symbols (atsc.cpp:37, field_sync.h:17,23), field parity
+ * (field_sync.h:10,25), oscillator table phase (offset.h:9,40-41). */
+typedef struct atsc_hip_stream_state {
+    uint64_t field_index;                               /* fields encoded so far (shared by all channels) */
+    uint8_t coded_tail[ATSC_HIP_INTERLEAVER_TAIL];      /* last 10608 RS-coded bytes of the previous field */
+    uint8_t last_group[12];                             /* last 12 interleaved bytes of the previous field  */
+    uint8_t z2[12];                                     /* precoder delay per trellis encoder               */
+    uint8_t z0_next[12];                                /* D1: Z0 of the next symbol                        */
+    uint8_t z0_prev[12];                                /* D2: Z0 of the last symbol                        */
+} atsc_hip_stream_state;
+
+int atsc_hip_export_state(atsc_hip_encoder* enc, int channel, atsc_hip_stream_state* out);
+/* Import sets the channel history; field_index moves the handle's field counter and re-derives the
+ * oscillator table T_f = T_0 (x) scale^f by the reference's fp32 recursion when it changes. */
+int atsc_hip_import_state(atsc_hip_encoder* enc, int channel, const atsc_hip_stream_state* in);
+
+/* Trellis parity of a span of fields encoded from zero trellis state: out36[0..11]=z2, [12..23]=z0_next,
+ * [24..35]=z0_prev contribution.  state_out = state_in XOR span_parity.  Valid after a batch. */
+int atsc_hip_span_parity(atsc_hip_encoder* enc, int channel, uint8_t* out36);
+
+/* Device pointer + byte size of the internal buffer written by a stage in the last batch (stage taps for
+ * the parity tests: coded bytes, interleaved bytes, symbols).  Layouts are documented in DESIGN.md. */
+int atsc_hip_stage_buffer(atsc_hip_encoder* enc, int stage, void** d_ptr, size_t* bytes, size_t* channel_stride);
+
+/* Per-stage kernel milliseconds of the last batch (needs ATSC_HIP_FLAG_TIMING; synchronizes). */
+int atsc_hip_last_timings(atsc_hip_encoder* enc, float* ms /* [ATSC_HIP_NSTAGES] */);
+
+/* Constant tables as the library built them (host copies), for table parity tests:
+ * which: 0 = 112 FIR taps (float), 1 = oscillator T0 (261248 complex64), 2 = scale (2 floats),
+ *        3 = PRBS bytes (58344), 4 = field sync even (820 B), 5 = field sync odd (820 B),
+ *        6 = RS generator g[0..20].  enc may be NULL (tables do not depend on the device; no GPU needed). */
+int atsc_hip_get_table(atsc_hip_encoder* enc, int which, void* h_out, size_t bytes);
+
+const char* atsc_hip_error_string(int code);
+const char* atsc_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ATSC_HIP_H */
