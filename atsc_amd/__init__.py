@@ -31,7 +31,8 @@ STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trell
 # every symbol include/atsc_hip.h declares
 EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_encode_batch",
            "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_export_state", "atsc_hip_import_state",
-           "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_get_table",
+           "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
+           "atsc_hip_batch_timings", "atsc_hip_get_table",
            "atsc_hip_error_string", "atsc_hip_version")
 
 
@@ -84,6 +85,8 @@ def load_library():
     L.atsc_hip_span_parity.argtypes = [vp, C.c_int, u8p]
     L.atsc_hip_stage_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.atsc_hip_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
+    L.atsc_hip_timing_reserve.argtypes = [vp, C.c_int]
+    L.atsc_hip_batch_timings.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.atsc_hip_get_table.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.atsc_hip_error_string.argtypes = [C.c_int]
     L.atsc_hip_error_string.restype = C.c_char_p
@@ -172,6 +175,14 @@ class Encoder:
     def last_timings(self):
         ms = (C.c_float * NSTAGES)()
         check(self.L.atsc_hip_last_timings(self.h, ms))
+        return {STAGE_NAMES[i]: ms[i] for i in range(NSTAGES)}
+
+    def timing_reserve(self, nslots):
+        check(self.L.atsc_hip_timing_reserve(self.h, nslots))
+
+    def batch_timings(self, batch):
+        ms = (C.c_float * NSTAGES)()
+        check(self.L.atsc_hip_batch_timings(self.h, batch, ms))
         return {STAGE_NAMES[i]: ms[i] for i in range(NSTAGES)}
 
     def table(self, which):

@@ -47,10 +47,15 @@ struct atsc_hip_encoder {
     float2* d_iq = nullptr;
     float2* h_iq_pinned = nullptr;
 
-    // timing
-    hipEvent_t ev[ATSC_HIP_NSTAGES + 1] = {};
+    // timing: a ring of event sets, one per batch, so a timed region can be read back afterwards
+    struct EventSet {
+        hipEvent_t ev[ATSC_HIP_NSTAGES + 1] = {};
+        bool recorded[ATSC_HIP_NSTAGES + 1] = {};
+    };
+    std::vector<EventSet> slots;
     bool ev_valid = false;
-    bool ev_recorded[ATSC_HIP_NSTAGES + 1] = {};
+    size_t batches = 0;         // batches launched since the last timing reset
+    EventSet* cur = nullptr;
 };
 
 extern "C" const char* atsc_hip_version(void) { return "atsc_hip 0.1 (gfx950)"; }
@@ -75,8 +80,9 @@ static int destroy_impl(atsc_hip_encoder* e) {
     hipFree(e->d_ts); hipFree(e->d_iq);
     if (e->h_ts_pinned) hipHostFree(e->h_ts_pinned);
     if (e->h_iq_pinned) hipHostFree(e->h_iq_pinned);
-    if (e->ev_valid)
-        for (auto& ev : e->ev) hipEventDestroy(ev);
+    for (auto& set : e->slots)
+        for (auto& ev : set.ev)
+            if (ev) hipEventDestroy(ev);
     delete e;
     return 0;
 }
@@ -146,7 +152,8 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     e->scale = make_float2(e->tab.scale[0], e->tab.scale[1]);
 
     if (cfg->flags & ATSC_HIP_FLAG_TIMING) {
-        for (auto& ev : e->ev) TRY_OR_FREE(hipEventCreate(&ev));
+        e->slots.resize(1);
+        for (auto& ev : e->slots[0].ev) TRY_OR_FREE(hipEventCreate(&ev));
         e->ev_valid = true;
     }
     TRY_OR_FREE(hipDeviceSynchronize());
@@ -158,10 +165,35 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
 namespace {
 
 void mark(atsc_hip_encoder* e, hipStream_t s, int idx) {
-    if (e->ev_valid) {
-        hipEventRecord(e->ev[idx], s);
-        e->ev_recorded[idx] = true;
+    if (e->cur) {
+        hipEventRecord(e->cur->ev[idx], s);
+        e->cur->recorded[idx] = true;
     }
+}
+
+// picks the event set of this batch (slot = batch number modulo the reserved ring)
+void begin_batch_timing(atsc_hip_encoder* e) {
+    e->cur = nullptr;
+    if (!e->ev_valid) return;
+    e->cur = &e->slots[e->batches % e->slots.size()];
+    std::fill(std::begin(e->cur->recorded), std::end(e->cur->recorded), false);
+    e->batches++;
+}
+
+int read_timings(atsc_hip_encoder* e, const atsc_hip_encoder::EventSet& set, float* ms) {
+    for (int i = 0; i < ATSC_HIP_NSTAGES; ++i) ms[i] = 0.f;
+    int prev = -1;  // each stage runs from its own mark to the next recorded mark
+    for (int i = 0; i <= ATSC_HIP_NSTAGES; ++i) {
+        if (!set.recorded[i]) continue;
+        if (prev >= 0) {
+            HIP_TRY(hipEventSynchronize(set.ev[i]));
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, set.ev[prev], set.ev[i]));
+            ms[prev] = t;
+        }
+        prev = i;
+    }
+    return ATSC_HIP_OK;
 }
 
 // stages a2..a6 (reference: atsc.cpp:80-84) for `fields` fields of every channel
@@ -208,7 +240,7 @@ extern "C" int atsc_hip_encode_batch(atsc_hip_encoder* e, const uint8_t* d_ts, i
     uint8_t* sym = d_sym ? d_sym : e->d_sym;
     e->last_fields = fields;
     const size_t sym_stride = (size_t)fields * kFieldSyms;
-    std::fill(std::begin(e->ev_recorded), std::end(e->ev_recorded), false);
+    begin_batch_timing(e);
     int rc = run_symbols(e, d_ts, fields, sym, sym_stride, s);
     if (rc) return rc;
     rc = run_mix_fir(e, sym, sym_stride, d_iq, fields, s);
@@ -225,7 +257,7 @@ extern "C" int atsc_hip_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, int f
     if ((reinterpret_cast<uintptr_t>(d_sym) & 15) || (reinterpret_cast<uintptr_t>(d_iq) & 15)) return ATSC_HIP_ERR_ARG;
     HIP_TRY(hipSetDevice(e->cfg.device));
     auto s = static_cast<hipStream_t>(stream);
-    std::fill(std::begin(e->ev_recorded), std::end(e->ev_recorded), false);
+    begin_batch_timing(e);
     int rc = run_mix_fir(e, d_sym, (size_t)fields * kFieldSyms, d_iq, fields, s);
     mark(e, s, ATSC_HIP_STAGE_STATE);
     if (rc) return rc;
@@ -379,22 +411,34 @@ extern "C" int atsc_hip_stage_buffer(atsc_hip_encoder* e, int stage, void** d_pt
 
 extern "C" int atsc_hip_last_timings(atsc_hip_encoder* e, float* ms) {
     if (!e || !ms) return ATSC_HIP_ERR_ARG;
+    if (!e->ev_valid || !e->cur) return ATSC_HIP_ERR_STATE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return read_timings(e, *e->cur, ms);
+}
+
+extern "C" int atsc_hip_timing_reserve(atsc_hip_encoder* e, int nslots) {
+    if (!e || nslots < 1) return ATSC_HIP_ERR_ARG;
     if (!e->ev_valid) return ATSC_HIP_ERR_STATE;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    for (int i = 0; i < ATSC_HIP_NSTAGES; ++i) ms[i] = 0.f;
-    // each stage runs from its own mark to the next recorded mark
-    int prev = -1;
-    for (int i = 0; i <= ATSC_HIP_NSTAGES; ++i) {
-        if (!e->ev_recorded[i]) continue;
-        if (prev >= 0) {
-            HIP_TRY(hipEventSynchronize(e->ev[i]));
-            float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, e->ev[prev], e->ev[i]));
-            ms[prev] = t;
-        }
-        prev = i;
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t old = e->slots.size();
+    if ((size_t)nslots > old) {
+        e->slots.resize(nslots);
+        for (size_t i = old; i < e->slots.size(); ++i)
+            for (auto& ev : e->slots[i].ev) HIP_TRY(hipEventCreate(&ev));
     }
+    for (auto& set : e->slots) std::fill(std::begin(set.recorded), std::end(set.recorded), false);
+    e->batches = 0;
+    e->cur = nullptr;
     return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_batch_timings(atsc_hip_encoder* e, int batch, float* ms) {
+    if (!e || !ms || batch < 0) return ATSC_HIP_ERR_ARG;
+    if (!e->ev_valid) return ATSC_HIP_ERR_STATE;
+    if ((size_t)batch >= e->batches || e->batches - (size_t)batch > e->slots.size()) return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return read_timings(e, e->slots[(size_t)batch % e->slots.size()], ms);
 }
 
 extern "C" int atsc_hip_get_table(atsc_hip_encoder* e, int which, void* h_out, size_t bytes) {

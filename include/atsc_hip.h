@@ -125,8 +125,14 @@ int atsc_hip_span_parity(atsc_hip_encoder* enc, int channel, uint8_t* out36);
  * the parity tests: coded bytes, interleaved bytes, symbols).  Layouts are documented in DESIGN.md. */
 int atsc_hip_stage_buffer(atsc_hip_encoder* enc, int stage, void** d_ptr, size_t* bytes, size_t* channel_stride);
 
-/* Per-stage kernel milliseconds of the last batch (needs ATSC_HIP_FLAG_TIMING; synchronizes). */
+/* Per-stage kernel milliseconds of the last batch (needs ATSC_HIP_FLAG_TIMING; synchronizes).
+ * No reference counterpart (the reference has no tracing): measurement support. */
 int atsc_hip_last_timings(atsc_hip_encoder* enc, float* ms /* [ATSC_HIP_NSTAGES] */);
+/* Reserve a ring of `nslots` HIP event sets and restart batch numbering at 0, so that every batch of a
+ * timed region keeps its own events (recorded on the stream the kernels are launched on) ... */
+int atsc_hip_timing_reserve(atsc_hip_encoder* enc, int nslots);
+/* ... and read batch `batch` (0-based since the last reserve; must still be in the ring) afterwards. */
+int atsc_hip_batch_timings(atsc_hip_encoder* enc, int batch, float* ms /* [ATSC_HIP_NSTAGES] */);
 
 /* Constant tables as the library built them (host copies), for table parity tests:
  * which: 0 = 112 FIR taps (float), 1 = oscillator T0 (261248 complex64), 2 = scale (2 floats),
