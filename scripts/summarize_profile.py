@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Summarize a gpurun_out/prof_<tag> directory (made by scripts/profile_gpu.sh) into profiles/<name>/.
+Copies the rocprofv3 kernel_stats CSV and writes one counters.csv (mean per launch, per kernel)."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
+trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+dur = collections.defaultdict(list)
+for r in csv.DictReader(open(trace)):
+    dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+names = sorted({c for k in acc for c in acc[k]})
+with open(os.path.join(dst, "counters.csv"), "w", newline="") as fo:
+    w = csv.writer(fo)
+    w.writerow(["kernel", "launches", "avg_us(trace run)", "min_us"] + names)
+    for k in sorted(acc):
+        if not k.startswith("atsc_k::"):
+            continue
+        d = dur.get(k, [0])
+        w.writerow([k, len(d), round(sum(d) / len(d), 1), round(min(d), 1)] +
+                   [round(sum(acc[k][n]) / len(acc[k][n])) if acc[k][n] else "" for n in names])
+print(open(os.path.join(dst, "counters.csv")).read())
