@@ -30,6 +30,7 @@ STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trell
 
 # every symbol include/atsc_hip.h declares
 EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_encode_batch",
+           "atsc_hip_encode_begin", "atsc_hip_encode_finish",
            "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_export_state", "atsc_hip_import_state",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
            "atsc_hip_batch_timings", "atsc_hip_get_table",
@@ -57,7 +58,7 @@ _lib = None
 
 def build(verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    out = subprocess.run(["make", "-C", os.path.join(ROOT, "atsc_amd", "csrc")], capture_output=True, text=True)
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "atsc_amd", "csrc"), "all"], capture_output=True, text=True)
     if verbose or out.returncode:
         print(out.stdout, out.stderr)
     if out.returncode:
@@ -78,6 +79,8 @@ def load_library():
     L.atsc_hip_destroy.restype = None
     L.atsc_hip_process.argtypes = [vp, u8p, C.c_uint, FIELD_CB, vp]
     L.atsc_hip_encode_batch.argtypes = [vp, u8p, C.c_int, u8p, vp, vp]
+    L.atsc_hip_encode_begin.argtypes = [vp, u8p, C.c_int, vp, vp]
+    L.atsc_hip_encode_finish.argtypes = [vp, vp, u8p, vp, vp]
     L.atsc_hip_encode_batch_host.argtypes = [vp, u8p, C.c_int, u8p, vp]
     L.atsc_hip_mix_fir.argtypes = [vp, u8p, C.c_int, vp, vp]
     L.atsc_hip_export_state.argtypes = [vp, C.c_int, C.POINTER(StreamState)]
@@ -138,6 +141,12 @@ class Encoder:
     # ---- batched device path
     def encode_batch(self, d_ts, fields, d_sym=None, d_iq=None, stream=None):
         check(self.L.atsc_hip_encode_batch(self.h, d_ts, fields, d_sym, d_iq, stream))
+
+    def encode_begin(self, d_ts, fields, d_span_parity=None, stream=None):
+        check(self.L.atsc_hip_encode_begin(self.h, d_ts, fields, d_span_parity, stream))
+
+    def encode_finish(self, d_carry_xor=None, d_sym=None, d_iq=None, stream=None):
+        check(self.L.atsc_hip_encode_finish(self.h, d_carry_xor, d_sym, d_iq, stream))
 
     def mix_fir(self, d_sym, fields, d_iq, stream=None):
         check(self.L.atsc_hip_mix_fir(self.h, d_sym, fields, d_iq, stream))

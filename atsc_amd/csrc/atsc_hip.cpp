@@ -37,6 +37,7 @@ struct atsc_hip_encoder {
     int osc_cur = 0;
     float2 scale{};
     uint64_t field_index = 0;
+    int pending_fields = 0;    // fields of a batch between encode_begin and encode_finish
     int last_fields = 0;       // field count of the last batch (internal symbol buffer is packed with it)
     void* d_tables = nullptr;
 
@@ -196,8 +197,9 @@ int read_timings(atsc_hip_encoder* e, const atsc_hip_encoder::EventSet& set, flo
     return ATSC_HIP_OK;
 }
 
-// stages a2..a6 (reference: atsc.cpp:80-84) for `fields` fields of every channel
-int run_symbols(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, uint8_t* d_sym, size_t sym_stride, hipStream_t s) {
+// stages a2..a4 + trellis parities (reference: atsc.cpp:80-82): everything that does not depend on the
+// trellis state entering the batch
+int run_front(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, hipStream_t s) {
     const int C = e->cfg.channels;
     mark(e, s, ATSC_HIP_STAGE_RAND_RS);
     launch_rand_rs(s, e->dtab, d_ts, (size_t)fields * kFieldTs, e->buf, C, fields);
@@ -205,8 +207,14 @@ int run_symbols(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, uint8_t* d
     launch_interleave(s, e->buf, C, fields);
     mark(e, s, ATSC_HIP_STAGE_TRELLIS_PAR);
     launch_trellis_parity(s, e->buf, C, fields);
+    return static_cast<int>(hipGetLastError());
+}
+
+// carries + stage a5/a6 (reference: atsc.cpp:83-84)
+int run_back(atsc_hip_encoder* e, const uint4* carry_xor, int fields, uint8_t* d_sym, size_t sym_stride, hipStream_t s) {
+    const int C = e->cfg.channels;
     mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);
-    launch_trellis_scan(s, e->buf, C, fields);
+    launch_trellis_scan(s, e->buf, carry_xor, C, fields);
     mark(e, s, ATSC_HIP_STAGE_TRELLIS_MAP);
     launch_trellis_map(s, e->dtab, e->buf, d_sym, sym_stride, C, fields, e->field_index);
     return static_cast<int>(hipGetLastError());
@@ -228,20 +236,44 @@ int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, vo
 
 }  // namespace
 
-extern "C" int atsc_hip_encode_batch(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, uint8_t* d_sym, void* d_iq,
-                                     void* stream) {
+static int check_batch_args(atsc_hip_encoder* e, const void* d_ts, int fields, const void* d_sym, const void* d_iq) {
     if (!e || !d_ts || fields < 1) return ATSC_HIP_ERR_ARG;
     if (fields > e->cfg.max_fields) return ATSC_HIP_ERR_TOO_LARGE;
     if ((reinterpret_cast<uintptr_t>(d_ts) & 3) || (reinterpret_cast<uintptr_t>(d_sym) & 15) ||
         (reinterpret_cast<uintptr_t>(d_iq) & 15))
         return ATSC_HIP_ERR_ARG;
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_encode_begin(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, void* d_span_parity,
+                                     void* stream) {
+    int rc = check_batch_args(e, d_ts, fields, nullptr, d_span_parity);
+    if (rc) return rc;
+    if (e->pending_fields) return ATSC_HIP_ERR_STATE;
     HIP_TRY(hipSetDevice(e->cfg.device));
     auto s = static_cast<hipStream_t>(stream);
+    begin_batch_timing(e);
+    rc = run_front(e, d_ts, fields, s);
+    if (rc) return rc;
+    if (d_span_parity) launch_span_parity(s, e->buf, static_cast<uint4*>(d_span_parity), e->cfg.channels, fields);
+    e->pending_fields = fields;
+    return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int atsc_hip_encode_finish(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_sym, void* d_iq,
+                                      void* stream) {
+    if (!e) return ATSC_HIP_ERR_ARG;
+    if (!e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if ((reinterpret_cast<uintptr_t>(d_sym) & 15) || (reinterpret_cast<uintptr_t>(d_iq) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_carry_xor) & 15))
+        return ATSC_HIP_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    auto s = static_cast<hipStream_t>(stream);
+    const int fields = e->pending_fields;
     uint8_t* sym = d_sym ? d_sym : e->d_sym;
     e->last_fields = fields;
     const size_t sym_stride = (size_t)fields * kFieldSyms;
-    begin_batch_timing(e);
-    int rc = run_symbols(e, d_ts, fields, sym, sym_stride, s);
+    int rc = run_back(e, static_cast<const uint4*>(d_carry_xor), fields, sym, sym_stride, s);
     if (rc) return rc;
     rc = run_mix_fir(e, sym, sym_stride, d_iq, fields, s);
     if (rc) return rc;
@@ -249,7 +281,17 @@ extern "C" int atsc_hip_encode_batch(atsc_hip_encoder* e, const uint8_t* d_ts, i
     launch_save_state(s, e->buf, e->cfg.channels, fields);
     mark(e, s, ATSC_HIP_NSTAGES);
     e->field_index += (uint64_t)fields;
+    e->pending_fields = 0;
     return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int atsc_hip_encode_batch(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, uint8_t* d_sym, void* d_iq,
+                                     void* stream) {
+    int rc = check_batch_args(e, d_ts, fields, d_sym, d_iq);
+    if (rc) return rc;
+    rc = atsc_hip_encode_begin(e, d_ts, fields, nullptr, stream);
+    if (rc) return rc;
+    return atsc_hip_encode_finish(e, nullptr, d_sym, d_iq, stream);
 }
 
 extern "C" int atsc_hip_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, int fields, void* d_iq, void* stream) {

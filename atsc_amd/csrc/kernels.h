@@ -50,7 +50,8 @@ void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, s
                     int channels, int fields);
 void launch_interleave(hipStream_t s, const Buffers& b, int channels, int fields);
 void launch_trellis_parity(hipStream_t s, const Buffers& b, int channels, int fields);
-void launch_trellis_scan(hipStream_t s, const Buffers& b, int channels, int fields);
+void launch_trellis_scan(hipStream_t s, const Buffers& b, const uint4* carry_xor, int channels, int fields);
+void launch_span_parity(hipStream_t s, const Buffers& b, uint4* d_out, int channels, int fields);
 void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride,
                         int channels, int fields, uint64_t field_base);
 void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields);

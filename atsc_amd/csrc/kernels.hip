@@ -229,10 +229,15 @@ void launch_trellis_parity(hipStream_t s, const Buffers& b, int channels, int fi
 // One wave per channel: exclusive XOR scan over fields*26 parts, seeded with the channel's carry.
 // Lane l owns one field (26 parts) per pass of 64 fields.
 __global__ __launch_bounds__(64) void k_trellis_scan(const uint4* __restrict__ par, uint4* __restrict__ cin,
-                                                     uint4* __restrict__ carry, uint4* __restrict__ span_par, int fields) {
+                                                     uint4* __restrict__ carry, uint4* __restrict__ span_par,
+                                                     const uint4* __restrict__ carry_xor, int fields) {
     const int lane = threadIdx.x;
     const int c = blockIdx.x;
-    const uint4 init = carry[c];
+    uint4 init = carry[c];
+    if (carry_xor) {  // time-split hand-off: state_in = own history XOR the parities of all earlier spans
+        const uint4 x = carry_xor[c];
+        init.x ^= x.x; init.y ^= x.y; init.z ^= x.z;
+    }
     uint32_t run[3] = {init.x, init.y, init.z};
     for (int f0 = 0; f0 < fields; f0 += 64) {
         const int f = f0 + lane;
@@ -267,8 +272,29 @@ __global__ __launch_bounds__(64) void k_trellis_scan(const uint4* __restrict__ p
     }
 }
 
-void launch_trellis_scan(hipStream_t s, const Buffers& b, int channels, int fields) {
-    hipLaunchKernelGGL(k_trellis_scan, dim3(channels), dim3(64), 0, s, b.par, b.cin, b.carry, b.span_par, fields);
+void launch_trellis_scan(hipStream_t s, const Buffers& b, const uint4* carry_xor, int channels, int fields) {
+    hipLaunchKernelGGL(k_trellis_scan, dim3(channels), dim3(64), 0, s, b.par, b.cin, b.carry, b.span_par, carry_xor,
+                       fields);
+}
+
+// XOR of all part parities of the batch, per channel: the span's contribution to the trellis state.
+__global__ __launch_bounds__(64) void k_span_parity(const uint4* __restrict__ par, uint4* __restrict__ out, int nparts) {
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x;
+    uint32_t t[3] = {0, 0, 0};
+    for (int i = lane; i < nparts; i += 64) {
+        const uint4 v = par[(size_t)c * nparts + i];
+        t[0] ^= v.x; t[1] ^= v.y; t[2] ^= v.z;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t[k] ^= __shfl_xor(t[k], d, 64);
+    if (lane == 0) out[c] = make_uint4(t[0], t[1], t[2], 0);
+}
+
+void launch_span_parity(hipStream_t s, const Buffers& b, uint4* d_out, int channels, int fields) {
+    hipLaunchKernelGGL(k_span_parity, dim3(channels), dim3(64), 0, s, b.par, d_out, fields * kParts);
 }
 
 // ======================================================================================= K4 map + sync

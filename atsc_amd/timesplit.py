@@ -1,0 +1,79 @@
+"""Time-splitting ONE transport stream at field boundaries across ranks (BASELINE config 5).
+
+The reference is strictly field-serial (src/atsc/atsc.cpp:59-90).  Everything a span of fields needs
+from the past is small:
+
+  * interleaver history  -- a function of the previous field's packets only, so a rank re-derives it
+                            from a one-field TS halo (no message);
+  * field parity, oscillator phase -- functions of the absolute field index (recomputed locally by
+                            atsc_hip_import_state with the reference's own fp32 recursion);
+  * trellis/precoder state -- GF(2)-linear: state_in(rank r) = XOR of the span parities of ranks < r.
+                            This is the ONE exchange step: an all-gather of 16 bytes per rank
+                            (RCCL over xGMI on GPUs, gloo in the CPU tests), then a local XOR fold;
+  * reserved sync symbols -- follow from the carries and the halo field's last interleaved group.
+
+No data-path tensor ever crosses GPUs; the message is latency-bound.
+"""
+import ctypes as C
+
+import torch
+
+import atsc_amd
+
+PARITY_BYTES = 16  # per channel: 3 little-endian words (encoders 0-3, 4-7, 8-11) + 1 pad word
+
+
+def exclusive_xor_over_ranks(span_parity, group=None):
+    """All-gather every rank's span parity and return the XOR of the parities of all EARLIER ranks.
+
+    span_parity: int32 tensor [4*channels] (the 16-byte-per-channel format of atsc_hip_encode_begin).
+    Works with the nccl (RCCL) backend on device tensors and with gloo (tensors are staged through the
+    host).  With no initialised process group (single process) it returns zeros.
+    """
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return torch.zeros_like(span_parity)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    backend = dist.get_backend(group)
+    buf = span_parity if backend == "nccl" else span_parity.cpu()
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    carry = torch.zeros_like(buf)
+    for q in range(rank):
+        carry ^= gathered[q]
+    return carry.to(span_parity.device)
+
+
+class TimeSplitEncoder:
+    """One rank's share of a time-split stream: fields [first_field, first_field + fields) of ONE channel."""
+
+    def __init__(self, fields, device=0):
+        self.fields = fields
+        self.device = device
+        self.enc = atsc_amd.Encoder(channels=1, max_fields=fields, device=device)
+
+    def prepare(self, first_field, halo_field_ts=None):
+        """Set up the history entering field `first_field`.  halo_field_ts: device u8 tensor with the 312
+        packets of field first_field-1 (None only for first_field == 0)."""
+        if first_field == 0:
+            return
+        assert halo_field_ts is not None and halo_field_ts.numel() == atsc_amd.FIELD_TS_BYTES
+        stream = torch.cuda.current_stream().cuda_stream
+        # warm-up field: leaves the right interleaver tail and last interleaved group in the handle
+        self.enc.encode_batch(halo_field_ts.data_ptr(), 1, None, None, stream)
+        st = self.enc.export_state(0)
+        for i in range(12):                      # trellis state comes from the exchange, not from the halo
+            st.z2[i] = st.z0_next[i] = st.z0_prev[i] = 0
+        st.field_index = first_field             # field parity + oscillator phase of the span start
+        self.enc.import_state(st, 0)
+
+    def encode(self, d_ts, d_sym, d_iq, group=None, exchange=exclusive_xor_over_ranks):
+        """begin -> exchange span parities -> finish.  d_ts/d_sym/d_iq: device tensors of this span."""
+        stream = torch.cuda.current_stream().cuda_stream
+        par = torch.zeros(4, dtype=torch.int32, device=d_ts.device)
+        self.enc.encode_begin(d_ts.data_ptr(), self.fields, par.data_ptr(), stream)
+        carry = exchange(par, group).contiguous()
+        self.enc.encode_finish(carry.data_ptr(), d_sym.data_ptr() if d_sym is not None else None,
+                               d_iq.data_ptr() if d_iq is not None else None, stream)
+        self._keep = (par, carry)  # keep the tensors alive until the stream has consumed them
+        return par

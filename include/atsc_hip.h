@@ -92,6 +92,20 @@ int atsc_hip_process(atsc_hip_encoder* enc, const uint8_t* h_pkts, unsigned coun
 int atsc_hip_encode_batch(atsc_hip_encoder* enc, const uint8_t* d_ts, int fields, uint8_t* d_sym, void* d_iq,
                           void* stream);
 
+/* The same batch in two halves, for the single-stream time-split case (BASELINE config 5).
+ * No reference counterpart (the reference is strictly field-serial); callers: multi-GPU hosts that split
+ * ONE stream at field boundaries.
+ *   begin : stages that do not depend on the trellis state entering the batch (randomizer, RS, interleaver,
+ *           per-part parities); writes the span parity per channel to d_span_parity (16 B per channel: three
+ *           little-endian words for encoders 0-3 / 4-7 / 8-11, one byte per encoder with bit0 = precoder
+ *           delay, bit1 = D1, bit2 = D2 contribution; fourth word 0), or skips it when NULL.
+ *   finish: d_carry_xor (same 16 B format per channel, device memory, or NULL) is XORed into the handle's own
+ *           trellis state -- for rank r of a time-split: the XOR of the span parities of all earlier ranks --
+ *           then scan, trellis/map/sync, mixer+FIR, state save.
+ * encode_batch == begin(NULL) + finish(NULL).  Everything stays asynchronous on `stream`. */
+int atsc_hip_encode_begin(atsc_hip_encoder* enc, const uint8_t* d_ts, int fields, void* d_span_parity, void* stream);
+int atsc_hip_encode_finish(atsc_hip_encoder* enc, const void* d_carry_xor, uint8_t* d_sym, void* d_iq, void* stream);
+
 /* Same, from/to host memory (pageable or pinned); synchronous.  h_sym / h_iq may be NULL. */
 int atsc_hip_encode_batch_host(atsc_hip_encoder* enc, const uint8_t* h_ts, int fields, uint8_t* h_sym, void* h_iq);
 

@@ -1,0 +1,84 @@
+"""CPU-side checks of the product boundary (no compute, no GPU needed):
+the C-ABI library loads, exports every symbol include/atsc_hip.h declares, builds the constant tables
+bit-identically to the oracle / golden fixtures, and refuses to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import atsc_amd
+from oracle_lib import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "atsc_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(atsc_hip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = atsc_amd.load_library()
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/atsc_hip.h but not exported"
+    assert sorted(atsc_amd.EXPORTS) == syms, "python binding list and header disagree"
+
+
+def test_header_cites_reference_for_each_entry_point():
+    txt = open(os.path.join(ROOT, "include", "atsc_hip.h")).read()
+    for anchor in ("src/atsc/atsc.h:7-16", "src/atsc/atsc.cpp:59-77", "src/atsc/atsc.cpp:93-95", "src/atsc/atsc.cpp:79-90"):
+        assert anchor in txt
+
+
+def test_struct_layout_matches_header():
+    # atsc_hip_stream_state: u64 + 10608 + 12*4 bytes, 8-byte aligned
+    assert C.sizeof(atsc_amd.StreamState) == (8 + 10608 + 48 + 7) // 8 * 8
+    assert C.sizeof(atsc_amd.Config) == 16
+
+
+def test_tables_match_oracle_and_golden(golden):
+    g, _ = golden
+    assert np.array_equal(atsc_amd.get_table(0).view(np.uint32), Oracle.taps().view(np.uint32))
+    assert [int(x) for x in atsc_amd.get_table(0).view(np.uint32)] == g["taps_bits"]
+    assert np.array_equal(atsc_amd.get_table(1).view(np.uint32), Oracle.osc0().view(np.uint32))
+    assert np.array_equal(atsc_amd.get_table(2).view(np.uint32), Oracle.scale().view(np.uint32))
+    assert np.array_equal(atsc_amd.get_table(3), Oracle.prbs())
+    assert np.array_equal(atsc_amd.get_table(4), Oracle.fsync(0))
+    assert np.array_equal(atsc_amd.get_table(5), Oracle.fsync(1))
+    assert np.array_equal(atsc_amd.get_table(6), Oracle.rs_gen())
+    taps = atsc_amd.get_table(0).view(np.uint32)
+    assert all(taps[k] == taps[110 - k] for k in range(111)) and taps[111] == 0  # k_mix_fir relies on this
+
+
+def test_error_strings_and_arg_checks():
+    lib = atsc_amd.load_library()
+    assert b"no CPU fallback" in lib.atsc_hip_error_string(-2)
+    assert lib.atsc_hip_create(None, None) == -1
+    assert lib.atsc_hip_encode_batch(None, None, 1, None, None, None) == -1
+    assert lib.atsc_hip_get_table(None, 99, C.c_void_p(1), 4) == -1
+
+
+def test_no_device_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(atsc_amd.AtscHipError, match="no HIP device"):
+        atsc_amd.Encoder(channels=1, max_fields=1)
+
+
+def test_product_never_touches_the_oracle():
+    """The product path must not import/link/call anything under oracle/ (tier rule 3)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "atsc_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("oracle_lib", "libatsc_oracle", "atsc_oracle", "libatsc_ref", "oracle/", "ref_probe"):
+                    assert needle not in txt, f"{f} refers to {needle}: the product must not use the checker"
+    import subprocess
+    out = subprocess.run(["ldd", atsc_amd.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "atsc_ref" not in out

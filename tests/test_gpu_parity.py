@@ -236,3 +236,37 @@ def test_errors(torch_cuda):
     enc2 = atsc_amd.Encoder(channels=2, max_fields=1)
     with pytest.raises(atsc_amd.AtscHipError):
         enc2.process(np.zeros(188, np.uint8), 1, lambda *a: None)  # streaming path is single-channel
+
+
+def test_config5_time_split_equals_continuous(torch_cuda):
+    """BASELINE config 5 on one GPU: 4 'ranks' x 3 fields, each a cold handle primed from a one-field TS halo,
+    trellis state handed over as the XOR of earlier span parities -> bit-identical symbols AND IQ."""
+    from atsc_amd.timesplit import TimeSplitEncoder
+    torch = torch_cuda
+    R, nf = 4, 3
+    ts = ts_mix(99, R * nf)
+    cont = atsc_amd.Encoder(channels=1, max_fields=R * nf)
+    sym_c, iq_c = run_device(torch, cont, ts, 1, R * nf)
+    d_ts = torch.from_numpy(ts).cuda()
+    ranks, pars = [], []
+    stream = torch.cuda.current_stream().cuda_stream
+    for r in range(R):
+        t = TimeSplitEncoder(nf)
+        halo = d_ts[(r * nf - 1) * FIELD_TS_BYTES:r * nf * FIELD_TS_BYTES] if r else None
+        t.prepare(r * nf, halo)
+        par = torch.zeros(4, dtype=torch.int32, device="cuda")
+        t.enc.encode_begin(d_ts[r * nf * FIELD_TS_BYTES:].data_ptr(), nf, par.data_ptr(), stream)
+        ranks.append(t)
+        pars.append(par)
+    syms, iqs = [], []
+    carry = torch.zeros(4, dtype=torch.int32, device="cuda")
+    for r in range(R):
+        d_sym = torch.empty(nf * FIELD_SYMBOLS, dtype=torch.uint8, device="cuda")
+        d_iq = torch.empty(nf * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+        ranks[r].enc.encode_finish(carry.data_ptr(), d_sym.data_ptr(), d_iq.data_ptr(), stream)
+        torch.cuda.synchronize()
+        syms.append(d_sym.cpu().numpy())
+        iqs.append(d_iq.cpu().numpy())
+        carry = carry ^ pars[r]
+    assert np.array_equal(np.concatenate(syms), sym_c)
+    assert np.array_equal(np.concatenate(iqs).view(np.uint32), iq_c.view(np.uint32))
