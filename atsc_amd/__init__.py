@@ -11,7 +11,7 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(ROOT, "atsc_amd", "lib", "libatsc_hip.so")
+LIB_PATH = os.environ.get("ATSC_HIP_LIB") or os.path.join(ROOT, "atsc_amd", "lib", "libatsc_hip.so")
 
 PACKETS_PER_FIELD = 312
 TS_PACKET_BYTES = 188

@@ -12,7 +12,11 @@
 // All byte/bit stages are bit-exact restatements of the closed forms in SURVEY.md Appendix A; the float
 // stage follows the reference's rounding for the oscillator recursion and sums the FIR in tap order.
 #include "kernels.h"
+#ifndef ATSC_ABLATE
+#define ATSC_ABLATE 0
+#endif
 
+#include <cstdlib>
 #include <utility>
 
 namespace atsc_k {
@@ -431,11 +435,13 @@ void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields
 // 56 unique values live in 28 aligned SGPR pairs for the whole kernel; op_sel picks the half of a pair
 // that is broadcast to both lanes of the packed FMA.
 __constant__ unsigned long long c_tap_pairs[28];
+hipError_t upload_taps_ffa(const float* taps112);
 
 hipError_t upload_taps(const float* taps112) {
     float pairs[56];
     for (int k = 0; k < 56; ++k) pairs[k] = taps112[k];
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_tap_pairs), pairs, sizeof pairs);
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_tap_pairs), pairs, sizeof pairs);
+    return e != hipSuccess ? e : upload_taps_ffa(taps112);
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -617,10 +623,230 @@ __global__ __launch_bounds__(kFirThreads) void k_mix_fir(const uint8_t* __restri
     }
 }
 
+// --------------------------------------------------------------------------------------- fast-FIR variant
+// 2-parallel fast FIR (FFA): with xe[m]=x[2m], xo[m]=x[2m+1], xs=xe+xo and the half-rate tap sets
+// h0[k]=c[2k], h1[k]=c[2k+1], hs=h0+h1 (56 taps each; h1[55]=c[111]=0):
+//     P[n] = sum_k h1[k] xe[n+k]    Q[n] = sum_k h0[k] xo[n+k]    S[n] = sum_k hs[k] xs[n+k]
+//     y[2n] = S[n] - P[n] - Q[n]          y[2n+1] = Q[n] + P[n+1]
+// i.e. 3 half-length filters per output pair instead of 4: a lane's 8 outputs cost 5*55 + 4*56 + 4*56 = 723
+// packed FMAs instead of 888.  Same staging, same register-resident oscillator, same sliding windows (now
+// over the three half-rate streams, LDS transposed by (index mod 4)).  h0/h1 come from the same 28 SGPR tap
+// pairs as the direct form; the 56 unsymmetric hs taps are read as LDS broadcasts into a small VGPR ring.
+// fp32 error vs the reference stays at the direct form's level (6e-7 measured; tolerance 1e-5).
+__constant__ float c_taps_hs[56];
+
+hipError_t upload_taps_ffa(const float* taps112) {
+    float hs[56];
+    for (int k = 0; k < 56; ++k) hs[k] = taps112[2 * k] + taps112[2 * k + 1];
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_taps_hs), hs, sizeof hs);
+}
+
+constexpr int kFfaNp = kFirR / 2;          // output pairs per lane (4)
+constexpr int kFfaSteps = kFfaNp + 55;     // half-rate samples a lane slides over (59)
+constexpr int kFfaDepth = 4;               // sample reads in flight per stream
+constexpr int kFfaTapRing = 6;             // hs tap pairs held in VGPRs
+constexpr int kFfaTapAhead = 3;            // pair m is read 2*kFfaTapAhead steps before its first use
+
+__device__ __forceinline__ void fir_fma_v(v2f& acc, const v2f x, const v2f tap_pair, const int odd) {
+    if (odd)
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(tap_pair));
+    else
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(tap_pair));
+}
+
+__device__ __forceinline__ constexpr int ffa_off(int j) { return (j % 4) * kFirCols + j / 4; }
+
+template <int J>
+__device__ __forceinline__ void ffa_step_pq(v2f (&P)[kFfaNp + 1], v2f (&Q)[kFfaNp], v2f (&re)[kFfaDepth],
+                                            v2f (&ro)[kFfaDepth], const v2f* se, const v2f* so,
+                                            const unsigned long long (&tp)[28]) {
+    const v2f xe = re[J % kFfaDepth];
+    const v2f xo = ro[J % kFfaDepth];
+    if constexpr (J + kFfaDepth < kFfaSteps) {
+        re[J % kFfaDepth] = se[ffa_off(J + kFfaDepth)];
+        ro[J % kFfaDepth] = so[ffa_off(J + kFfaDepth)];
+    }
+#pragma unroll
+    for (int r = 0; r <= kFfaNp; ++r) {
+        const int k = J - r;
+        if (k >= 0 && k <= 54) fir_fma(P[r], xe, tp, 2 * k + 1);   // h1[k] = c[2k+1]
+    }
+#pragma unroll
+    for (int r = 0; r < kFfaNp; ++r) {
+        const int k = J - r;
+        if (k >= 0 && k <= 55) fir_fma(Q[r], xo, tp, 2 * k);       // h0[k] = c[2k]
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int... Js>
+__device__ __forceinline__ void ffa_steps_pq(v2f (&P)[kFfaNp + 1], v2f (&Q)[kFfaNp], v2f (&re)[kFfaDepth],
+                                             v2f (&ro)[kFfaDepth], const v2f* se, const v2f* so,
+                                             const unsigned long long (&tp)[28], std::integer_sequence<int, Js...>) {
+    (ffa_step_pq<Js>(P, Q, re, ro, se, so, tp), ...);
+}
+
+template <int J>
+__device__ __forceinline__ void ffa_step_s(v2f (&S)[kFfaNp], v2f (&rs)[kFfaDepth], v2f (&tr)[kFfaTapRing],
+                                           const v2f* ss, const v2f* taps) {
+    const v2f xs = rs[J % kFfaDepth];
+    if constexpr (J + kFfaDepth < kFfaSteps) rs[J % kFfaDepth] = ss[ffa_off(J + kFfaDepth)];
+    if constexpr ((J % 2) == 0 && J / 2 + kFfaTapAhead < 28) tr[(J / 2 + kFfaTapAhead) % kFfaTapRing] = taps[J / 2 + kFfaTapAhead];
+#pragma unroll
+    for (int r = 0; r < kFfaNp; ++r) {
+        const int k = J - r;
+        if (k >= 0 && k <= 55) fir_fma_v(S[r], xs, tr[(k >> 1) % kFfaTapRing], k & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int... Js>
+__device__ __forceinline__ void ffa_steps_s(v2f (&S)[kFfaNp], v2f (&rs)[kFfaDepth], v2f (&tr)[kFfaTapRing],
+                                            const v2f* ss, const v2f* taps, std::integer_sequence<int, Js...>) {
+    (ffa_step_s<Js>(S, rs, tr, ss, taps), ...);
+}
+
+__global__ __launch_bounds__(kFirThreads) void k_mix_fir_ffa(const uint8_t* __restrict__ sym, size_t sym_stride,
+                                                             float2* __restrict__ iq, size_t iq_stride,
+                                                             const float2* __restrict__ osc_in,
+                                                             float2* __restrict__ osc_out, float2 scale, int channels,
+                                                             int fields, int ch_per_group, int f_per_group) {
+    __shared__ float2 s_e[4 * kFirCols];  // x[2m]            transposed by (m mod 4)
+    __shared__ float2 s_o[4 * kFirCols];  // x[2m+1]
+    __shared__ float2 s_s[4 * kFirCols];  // x[2m] + x[2m+1]
+    __shared__ float2 s_hs[28];           // hs tap pairs
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int c_lo = blockIdx.y * ch_per_group, c_hi = min(channels, c_lo + ch_per_group);
+    const int f_lo = blockIdx.z * f_per_group, f_hi = min(fields, f_lo + f_per_group);
+    const bool halo = tid < (kFirCols - kFirThreads);
+    const int pos_main = tile * kFirTile + kFirR * tid;
+    const int pos_halo = (tile + 1) * kFirTile + kFirR * tid;
+
+    unsigned long long tp[28];
+#pragma unroll
+    for (int m = 0; m < 28; ++m) tp[m] = c_tap_pairs[m];
+    if (tid < 28) s_hs[tid] = make_float2(c_taps_hs[2 * tid], c_taps_hs[2 * tid + 1]);
+
+    float2 tm[kFirR], th[kFirR];
+    load_osc8(osc_in, pos_main, true, tm);
+    load_osc8(osc_in, pos_halo, halo, th);
+    for (int n = 0; n < f_lo; ++n) {
+#pragma unroll
+        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
+    }
+
+    const int out0 = tile * kFirTile + kFirR * tid;  // first output of this lane (lane = pairs 4*tid .. 4*tid+3)
+    const bool lane_on = out0 < kFieldSyms;
+
+    SymRegs sm, sh;
+    {
+        const uint8_t* sf = sym + (size_t)c_lo * sym_stride + (size_t)f_lo * kFieldSyms;
+        sm = load_syms(sf, pos_main);
+        sh = halo ? load_syms(sf, pos_halo) : SymRegs{0u, 0u, false};
+    }
+
+    for (int f = f_lo; f < f_hi; ++f) {
+        for (int c = c_lo; c < c_hi; ++c) {
+            // ---- stage: mixed samples split into even / odd / sum half-rate streams
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float x0 = sm.on ? level_of(p < 2 ? sm.lo : sm.hi, (2 * p) & 3) : 0.0f;
+                const float x1 = sm.on ? level_of(p < 2 ? sm.lo : sm.hi, (2 * p + 1) & 3) : 0.0f;
+                const float2 a = make_float2(__fmul_rn(x0, tm[2 * p].x), __fmul_rn(x0, tm[2 * p].y));
+                const float2 b = make_float2(__fmul_rn(x1, tm[2 * p + 1].x), __fmul_rn(x1, tm[2 * p + 1].y));
+                s_e[p * kFirCols + tid] = a;
+                s_o[p * kFirCols + tid] = b;
+                s_s[p * kFirCols + tid] = make_float2(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y));
+            }
+            if (halo) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float x0 = sh.on ? level_of(p < 2 ? sh.lo : sh.hi, (2 * p) & 3) : 0.0f;
+                    const float x1 = sh.on ? level_of(p < 2 ? sh.lo : sh.hi, (2 * p + 1) & 3) : 0.0f;
+                    const float2 a = make_float2(__fmul_rn(x0, th[2 * p].x), __fmul_rn(x0, th[2 * p].y));
+                    const float2 b = make_float2(__fmul_rn(x1, th[2 * p + 1].x), __fmul_rn(x1, th[2 * p + 1].y));
+                    s_e[p * kFirCols + kFirThreads + tid] = a;
+                    s_o[p * kFirCols + kFirThreads + tid] = b;
+                    s_s[p * kFirCols + kFirThreads + tid] = make_float2(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y));
+                }
+            }
+            __syncthreads();
+
+            // ---- prefetch the next (channel, field) symbols
+            {
+                int cn = c + 1, fn = f;
+                if (cn == c_hi) { cn = c_lo; fn = f + 1; }
+                if (fn < f_hi) {
+                    const uint8_t* sf = sym + (size_t)cn * sym_stride + (size_t)fn * kFieldSyms;
+                    sm = load_syms(sf, pos_main);
+                    if (halo) sh = load_syms(sf, pos_halo);
+                }
+            }
+
+            const v2f* se = reinterpret_cast<const v2f*>(s_e) + tid;
+            const v2f* so = reinterpret_cast<const v2f*>(s_o) + tid;
+            const v2f* ss = reinterpret_cast<const v2f*>(s_s) + tid;
+            const v2f* taps = reinterpret_cast<const v2f*>(s_hs);
+
+            v2f P[kFfaNp + 1], Q[kFfaNp], S[kFfaNp];
+#pragma unroll
+            for (int r = 0; r <= kFfaNp; ++r) P[r] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < kFfaNp; ++r) { Q[r] = (v2f){0.f, 0.f}; S[r] = (v2f){0.f, 0.f}; }
+
+            {   // phase 1: P and Q share the walk over the even / odd streams
+                v2f re[kFfaDepth], ro[kFfaDepth];
+#pragma unroll
+                for (int j = 0; j < kFfaDepth; ++j) { re[j] = se[ffa_off(j)]; ro[j] = so[ffa_off(j)]; }
+                __builtin_amdgcn_sched_barrier(0);
+                ffa_steps_pq(P, Q, re, ro, se, so, tp, std::make_integer_sequence<int, kFfaSteps>{});
+            }
+            {   // phase 2: S over the sum stream, taps from LDS broadcasts
+                v2f rs[kFfaDepth], tr[kFfaTapRing];
+#pragma unroll
+                for (int j = 0; j < kFfaDepth; ++j) rs[j] = ss[ffa_off(j)];
+#pragma unroll
+                for (int m = 0; m < kFfaTapAhead; ++m) tr[m] = taps[m];
+                __builtin_amdgcn_sched_barrier(0);
+                ffa_steps_s(S, rs, tr, ss, taps, std::make_integer_sequence<int, kFfaSteps>{});
+            }
+#if ATSC_ABLATE == 1
+            {
+#pragma unroll
+                for (int r = 0; r < kFfaNp; ++r) {
+                    const v2f y0 = (S[r] - P[r]) - Q[r];
+                    const v2f y1 = Q[r] + P[r + 1];
+                    asm volatile("" ::"v"(y0), "v"(y1));
+                }
+            }
+#else
+            if (lane_on) {
+                float4* dst = reinterpret_cast<float4*>(iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + out0);
+#pragma unroll
+                for (int r = 0; r < kFfaNp; ++r) {
+                    const v2f y0 = (S[r] - P[r]) - Q[r];
+                    const v2f y1 = Q[r] + P[r + 1];
+                    dst[r] = make_float4(y0.x, y0.y, y1.x, y1.y);
+                }
+            }
+#endif
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
+    }
+
+    if (blockIdx.y == 0 && f_hi == fields && pos_main < kPaddedSyms) {
+        float4* p = reinterpret_cast<float4*>(osc_out + pos_main);
+#pragma unroll
+        for (int j = 0; j < kFirR / 2; ++j) p[j] = make_float4(tm[2 * j].x, tm[2 * j].y, tm[2 * j + 1].x, tm[2 * j + 1].y);
+    }
+}
+
 void launch_mix_fir(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
                     const float2* osc_in, float2* osc_out, float2 scale, int channels, int fields) {
     // Decomposition: 128 tiles x channel groups x field groups, aiming at >= ~2048 blocks (8 per CU).
-    const int target = 2048 / kFirTiles;  // 16 (channel group, field group) pairs
+    static const int target_blocks = [] { const char* e = getenv("ATSC_FIR_BLOCKS"); return e ? atoi(e) : 2048; }();
+    const int target = target_blocks / kFirTiles;  // (channel group, field group) pairs
     int ngroups_c = channels < target ? channels : target;
     int ch_per_group = (channels + ngroups_c - 1) / ngroups_c;
     ngroups_c = (channels + ch_per_group - 1) / ch_per_group;
@@ -630,8 +856,13 @@ void launch_mix_fir(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, floa
     int f_per_group = (fields + ngroups_f - 1) / ngroups_f;
     ngroups_f = (fields + f_per_group - 1) / f_per_group;
     dim3 grid(kFirTiles, ngroups_c, ngroups_f);
-    hipLaunchKernelGGL(k_mix_fir, grid, dim3(kFirThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_in, osc_out,
-                       scale, channels, fields, ch_per_group, f_per_group);
+    static const int variant = [] { const char* e = getenv("ATSC_FIR_VARIANT"); return e ? atoi(e) : 1; }();
+    if (variant == 0)
+        hipLaunchKernelGGL(k_mix_fir, grid, dim3(kFirThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_in, osc_out,
+                           scale, channels, fields, ch_per_group, f_per_group);
+    else
+        hipLaunchKernelGGL(k_mix_fir_ffa, grid, dim3(kFirThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_in,
+                           osc_out, scale, channels, fields, ch_per_group, f_per_group);
 }
 
 // ======================================================================================= K6 oscillator advance
