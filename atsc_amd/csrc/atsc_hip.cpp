@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -34,6 +35,7 @@ struct atsc_hip_encoder {
     uint8_t* d_sym = nullptr;   // internal symbol buffer [channels][max_fields][260416]
     size_t sym_stride = 0;
     float2* d_osc[2] = {nullptr, nullptr};
+    float2* d_osc_tab = nullptr;  // [max_fields][261248] oscillator table of the current batch
     int osc_cur = 0;
     float2 scale{};
     uint64_t field_index = 0;
@@ -77,7 +79,7 @@ static int destroy_impl(atsc_hip_encoder* e) {
     hipSetDevice(e->cfg.device);
     hipFree(e->buf.coded); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
     hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
-    hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_tables);
+    hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc_tab); hipFree(e->d_tables);
     hipFree(e->d_ts); hipFree(e->d_iq);
     if (e->h_ts_pinned) hipHostFree(e->h_ts_pinned);
     if (e->h_iq_pinned) hipHostFree(e->h_iq_pinned);
@@ -127,6 +129,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     e->dtab.rs_rows = reinterpret_cast<const uint4*>(tb + off_rows);
     e->dtab.fsync = tb + off_fs;
     TRY_OR_FREE(upload_taps(e->tab.taps));
+    TRY_OR_FREE(upload_fft_tables(e->tab.taps));
 
     // per-channel working buffers
     e->buf.max_fields = cfg->max_fields;
@@ -150,6 +153,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     // oscillator state (double-buffered), T_0 and the per-field rotation
     for (int i = 0; i < 2; ++i) TRY_OR_FREE(hipMalloc(&e->d_osc[i], sizeof(float2) * kPaddedSyms));
     TRY_OR_FREE(hipMemcpy(e->d_osc[0], e->tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice));
+    TRY_OR_FREE(hipMalloc(&e->d_osc_tab, sizeof(float2) * kPaddedSyms * F));
     e->scale = make_float2(e->tab.scale[0], e->tab.scale[1]);
 
     if (cfg->flags & ATSC_HIP_FLAG_TIMING) {
@@ -225,7 +229,11 @@ int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, vo
     mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
     const float2* oin = e->d_osc[e->osc_cur];
     float2* oout = e->d_osc[e->osc_cur ^ 1];
-    if (d_iq)
+    static const int variant = [] { const char* v = getenv("ATSC_FIR_VARIANT"); return v ? atoi(v) : 2; }();
+    if (d_iq && variant == 2)
+        launch_mix_fir_fft(s, d_sym, sym_stride, static_cast<float2*>(d_iq), (size_t)fields * kFieldSyms, oin, oout,
+                           e->d_osc_tab, e->scale, C, fields);
+    else if (d_iq)
         launch_mix_fir(s, d_sym, sym_stride, static_cast<float2*>(d_iq), (size_t)fields * kFieldSyms, oin, oout, e->scale,
                        C, fields);
     else

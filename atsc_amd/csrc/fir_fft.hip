@@ -1,0 +1,299 @@
+// gfx950 mixer + RRC FIR as overlap-save fast convolution.
+//
+//   y[i] = sum_{k<111} c[k] * x[i+k] * T_f[i+k]          (reference: offset.h:11-45, filter.h:9-69)
+//
+// The direct form costs 111 packed FMAs per output and is fp32-VALU-bound at ~0.2 of the HBM roof.  Here
+// the field is cut into 1024-sample blocks that advance by 896 (overlap 128 >= 110); each block is
+// transformed (1024-point complex FFT), multiplied by the conjugate tap spectrum and transformed back:
+// ~38 packed VALU instructions per output.  fp32 round-off stays at 2.4e-7 of full scale (the direct
+// in-order sum: 5.4e-7; tolerance 1e-5).
+//
+// Mapping: 1024 = 32 x 32.  One FFT block is owned by 32 lanes (half a wave); every lane keeps 32 complex
+// points in registers and runs four 32-point in-register FFTs per block (two forward, two inverse), with
+// ONE transposition through LDS per 1024-point transform:
+//   forward  pass 1: lane n1 transforms x[n1 + 32*n2] over n2 -> kA; twiddle W^(n1*kA); LDS transpose
+//            pass 2: lane kA transforms over n1 -> X[kA + 32*kB]
+//   multiply by Hs[kA + 32*kB] = conj(FFT(c))/1024
+//   inverse  pass 1: lane kA transforms over kB -> nB; twiddle W^-(nB*kA); LDS transpose
+//            pass 2: lane nB transforms over kA -> y[nB + 32*nA]
+// so both the symbol loads (32 consecutive bytes per lane, re-spread through LDS) and the IQ stores (32
+// lanes x 8 B = 256 contiguous, 128-byte aligned bytes per output row) are coalesced and no bit-reversal
+// pass exists: every 32-point transform is decimation-in-time with its input registers *named* in
+// bit-reversed order.  Half-waves never synchronise with each other: LDS transposes are private to the
+// 32 lanes of a block and ordered by the wave's in-order LDS queue.
+//
+// The oscillator T_f is read from a per-field table built once per batch by k_osc_table with the
+// reference's exact fp32 recursion (offset.h:35-41), so a task (block, field, channel group) needs no
+// history and the grid is a flat list of equal tasks.
+#include "kernels.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace atsc_k {
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int kRowPad = 33;                       // LDS row stride (complex) of a 32x32 transpose: odd -> conflict-free
+constexpr int kHalfWaves = 16;                    // FFT blocks per workgroup step (512 threads)
+constexpr int kFftThreads = 32 * kHalfWaves;
+
+__device__ float2 g_fft_tab[2048];                // [0,1024): TW[a][b] = W^(a*b);  [1024,2048): Hs[kB][kA]
+
+__host__ __device__ constexpr int br5(int p) {
+    return ((p & 1) << 4) | ((p & 2) << 2) | (p & 4) | ((p & 8) >> 2) | ((p & 16) >> 4);
+}
+
+// cos / sin of 2*pi*m/32, m = 0..15
+__device__ constexpr float kC32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                                       0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f,
+                                       0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f,
+                                       -0.55557023301960222474f, -0.70710678118654752440f, -0.83146961230254523708f,
+                                       -0.92387953251128675613f, -0.98078528040323044913f};
+__device__ constexpr float kS32[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f,
+                                       0.70710678118654752440f, 0.83146961230254523708f, 0.92387953251128675613f,
+                                       0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f,
+                                       0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                                       0.38268343236508977173f, 0.19509032201612826785f};
+
+__device__ __forceinline__ v2f swap(v2f v) { return __builtin_shufflevector(v, v, 1, 0); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// a * w, w = (wr, wi)
+__device__ __forceinline__ v2f cmul(v2f a, v2f w) {
+    const v2f t = a * (v2f){w.x, w.x};
+    return vfma(swap(a), (v2f){-w.y, w.y}, t);
+}
+__device__ __forceinline__ v2f cmul_conj(v2f a, v2f w) {
+    const v2f t = a * (v2f){w.x, w.x};
+    return vfma(swap(a), (v2f){w.y, -w.y}, t);
+}
+
+// One decimation-in-time butterfly (a, b) -> (a + w b, a - w b), w = W_32^(+-m) (forward: exp(-j..)).
+template <bool INV>
+__device__ __forceinline__ void butterfly(v2f& a, v2f& b, const int m) {
+    constexpr float r = 0.70710678118654752440f;
+    if (m == 0) {
+        const v2f t = a;
+        a = t + b;
+        b = t - b;
+    } else if (m == 8) {  // w = -j (forward), +j (inverse)
+        const v2f bj = INV ? (v2f){-b.y, b.x} : (v2f){b.y, -b.x};
+        const v2f t = a;
+        a = t + bj;
+        b = t - bj;
+    } else if (m == 4 || m == 12) {
+        // forward m=4: r(1-j)   m=12: -r(1+j);   inverse m=4: r(1+j)   m=12: -r(1-j)
+        const bool minus_j = (m == 4) != INV;
+        const v2f s = minus_j ? (v2f){b.x + b.y, b.y - b.x} : (v2f){b.x - b.y, b.x + b.y};
+        const float g = (m == 4) ? r : -r;
+        const v2f t = a;
+        a = vfma(s, (v2f){g, g}, t);
+        b = vfma(s, (v2f){-g, -g}, t);
+    } else {
+        const float wr = kC32[m];
+        const float wi = INV ? kS32[m] : -kS32[m];
+        const v2f u = vfma(b, (v2f){wr, wr}, a);
+        const v2f p = vfma(swap(b), (v2f){-wi, wi}, u);
+        b = vfma(a, (v2f){2.0f, 2.0f}, -p);
+        a = p;
+    }
+}
+
+// 32-point DIT FFT in registers: x[p] holds input element br5(p); on return x[k] holds output element k.
+template <bool INV>
+__device__ __forceinline__ void fft32(v2f (&x)[32]) {
+#pragma unroll
+    for (int half = 1; half < 32; half <<= 1) {
+#pragma unroll
+        for (int g = 0; g < 32; g += 2 * half) {
+#pragma unroll
+            for (int i = 0; i < half; ++i) butterfly<INV>(x[g + i], x[g + i + half], i * (16 / half));
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in order; this only stops the compiler from moving them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float level_of_byte(uint32_t v) {
+    return __fmaf_rn((float)v, 2.0f, -5.75f);  // 2v - 7 + 1.25 (signal.h:16), exact
+}
+
+// 32 consecutive symbols of the padded field starting at pos (multiple of 32): the field itself, then the copy of
+// its sync head (field_sync.h:16).  Positions >= 260416 + 820 are never reached (host-checked geometry).
+__device__ __forceinline__ void load_syms32(const uint8_t* sym_f, int pos, uint4& lo, uint4& hi) {
+    const int src = pos < kFieldSyms ? pos : pos - kFieldSyms;
+    const uint4* p = reinterpret_cast<const uint4*>(sym_f + src);
+    lo = p[0];
+    hi = p[1];
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __restrict__ sym, size_t sym_stride,
+                                                             float2* __restrict__ iq, size_t iq_stride,
+                                                             const float2* __restrict__ osc_tab, int channels,
+                                                             int fields, int ch_per_group, int ch_groups) {
+    __shared__ float2 s_tw[1024];
+    __shared__ float2 s_h[1024];
+    __shared__ float2 s_x[kHalfWaves][32 * kRowPad];
+    const int tid = threadIdx.x;
+    const int t = tid & 31;
+    const int hw = tid >> 5;
+
+    for (int i = tid; i < 1024; i += kFftThreads) {
+        s_tw[i] = g_fft_tab[i];
+        s_h[i] = g_fft_tab[1024 + i];
+    }
+    __syncthreads();
+
+    // task = (FFT block b, field f, channel group cg)
+    const long task = (long)blockIdx.x * kHalfWaves + hw;
+    const int b = (int)(task % kFftBlocks);
+    const long g = task / kFftBlocks;
+    const int cg = (int)(g % ch_groups);
+    const int f = (int)(g / ch_groups);
+    if (f >= fields) return;
+    const int c_lo = cg * ch_per_group, c_hi = min(channels, c_lo + ch_per_group);
+
+    const int base = b * kFftValid;                       // first sample / first output of the block
+    const int rows_valid = min(kFftValid, kFieldSyms - base) >> 5;  // output rows of 32 that exist (28, or 18 at the end)
+
+    // oscillator slice of the block, in the register order of the first transform: o[p] = T_f[base + t + 32*br5(p)]
+    v2f o[32];
+    {
+        const float2* of = osc_tab + (size_t)f * kPaddedSyms + base + t;
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const float2 v = of[32 * br5(p)];
+            o[p] = (v2f){v.x, v.y};
+        }
+    }
+
+    float2* xs = s_x[hw];
+    const v2f* xsv = reinterpret_cast<const v2f*>(xs);
+    const uint8_t* xs8 = reinterpret_cast<const uint8_t*>(xs);
+    const v2f* tw = reinterpret_cast<const v2f*>(s_tw);
+    const v2f* hs = reinterpret_cast<const v2f*>(s_h);
+
+    uint4 s_lo, s_hi;
+    load_syms32(sym + (size_t)c_lo * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        // ---- symbols: 32 consecutive bytes per lane -> LDS -> byte t + 32*j per lane
+        reinterpret_cast<uint4*>(xs)[2 * t] = s_lo;
+        reinterpret_cast<uint4*>(xs)[2 * t + 1] = s_hi;
+        wave_lds_sync();
+        if (c + 1 < c_hi)
+            load_syms32(sym + (size_t)(c + 1) * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
+
+        v2f x[32];
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const float lv = level_of_byte(xs8[t + 32 * br5(p)]);
+            x[p] = o[p] * (v2f){lv, lv};  // x * T: two single-rounded products (offset.h:24-31)
+        }
+        wave_lds_sync();
+
+        // ---- forward pass 1 (over n2), twiddle, transpose
+        fft32<false>(x);
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            const v2f v = k == 0 ? x[0] : cmul(x[k], tw[32 * k + t]);
+            *reinterpret_cast<v2f*>(&xs[k * kRowPad + t]) = v;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < 32; ++p) x[p] = xsv[t * kRowPad + br5(p)];
+        wave_lds_sync();
+
+        // ---- forward pass 2 (over n1), spectrum multiply; x[kB] = X[t + 32*kB] is the inverse's input kB
+        fft32<false>(x);
+        v2f y[32];
+#pragma unroll
+        for (int p = 0; p < 32; ++p) y[p] = cmul(x[br5(p)], hs[32 * br5(p) + t]);
+
+        // ---- inverse pass 1 (over kB), twiddle, transpose
+        fft32<true>(y);
+#pragma unroll
+        for (int n = 0; n < 32; ++n) {
+            const v2f v = n == 0 ? y[0] : cmul_conj(y[n], tw[32 * n + t]);
+            *reinterpret_cast<v2f*>(&xs[n * kRowPad + t]) = v;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int p = 0; p < 32; ++p) y[p] = xsv[t * kRowPad + br5(p)];
+        wave_lds_sync();
+
+        // ---- inverse pass 2 (over kA) -> y[t + 32*nA]; rows nA < 28 are free of circular wrap
+        fft32<true>(y);
+        float2* dst = iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + base + t;
+#pragma unroll
+        for (int n = 0; n < kFftValid / 32; ++n)
+            if (n < rows_valid) dst[32 * n] = make_float2(y[n].x, y[n].y);
+    }
+}
+
+// Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41)
+__global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in, float2* __restrict__ tab,
+                                                   float2* __restrict__ out, float2 sc, int fields) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kPaddedSyms) return;
+    float2 t = in[i];
+    for (int f = 0; f < fields; ++f) {
+        tab[(size_t)f * kPaddedSyms + i] = t;
+        const float t2 = __fmul_rn(t.y, sc.y);
+        const float t3 = __fmul_rn(t.x, sc.y);
+        t = make_float2(__fmaf_rn(t.x, sc.x, -t2), __fmaf_rn(t.y, sc.x, t3));
+    }
+    out[i] = t;
+}
+
+hipError_t upload_fft_tables(const float* taps112) {
+    static_assert(kFftBlocks * kFftValid >= kFieldSyms, "blocks must cover the field");
+    static_assert((kFftBlocks - 1) * kFftValid + kFftN <= kFieldSyms + 820, "look-ahead must stay inside the sync-head copy");
+    static_assert(kFftN - kFftValid >= 110, "overlap must cover the filter");
+    static_assert((kFieldSyms - (kFftBlocks - 1) * kFftValid) % 32 == 0, "field end must fall on a 32-sample row");
+    std::vector<float> h(2 * 2048);
+    const double w0 = -2.0 * M_PI / kFftN;
+    for (int a = 0; a < 32; ++a)
+        for (int b = 0; b < 32; ++b) {
+            h[2 * (32 * a + b)] = (float)std::cos(w0 * a * b);
+            h[2 * (32 * a + b) + 1] = (float)std::sin(w0 * a * b);
+        }
+    // Hs[k] = conj(sum_n c[n] W^(n k)) / N, stored [kB][kA] with k = kA + 32 kB
+    for (int k = 0; k < kFftN; ++k) {
+        double re = 0, im = 0;
+        for (int n = 0; n < 111; ++n) {
+            re += (double)taps112[n] * std::cos(w0 * n * k);
+            im += (double)taps112[n] * std::sin(w0 * n * k);
+        }
+        const int kA = k & 31, kB = k >> 5;
+        h[2 * (1024 + 32 * kB + kA)] = (float)(re / kFftN);
+        h[2 * (1024 + 32 * kB + kA) + 1] = (float)(-im / kFftN);
+    }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fft_tab), h.data(), sizeof(float) * h.size());
+}
+
+void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
+                        const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int channels, int fields) {
+    hipLaunchKernelGGL(k_osc_table, dim3((kPaddedSyms + 255) / 256), dim3(256), 0, s, osc_in, osc_tab, osc_out, scale,
+                       fields);
+    static const int cpg_env = [] { const char* e = getenv("ATSC_FIR_CH_PER_TASK"); return e ? atoi(e) : 8; }();
+    const int ch_per_group = channels < cpg_env ? channels : cpg_env;
+    const int ch_groups = (channels + ch_per_group - 1) / ch_per_group;
+    const long tasks = (long)kFftBlocks * ch_groups * fields;
+    const unsigned grid = (unsigned)((tasks + kHalfWaves - 1) / kHalfWaves);
+    hipLaunchKernelGGL(k_mix_fir_fft, dim3(grid), dim3(kFftThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_tab,
+                       channels, fields, ch_per_group, ch_groups);
+}
+
+}  // namespace atsc_k
