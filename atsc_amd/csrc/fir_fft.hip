@@ -37,11 +37,12 @@ namespace {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-constexpr int kRowPad = 33;                       // LDS row stride (complex) of a 32x32 transpose: odd -> conflict-free
+constexpr int kRowPad = 34;                       // LDS row stride (complex) of a 32x32 transpose: 16-byte aligned rows, column
+                                                  // writes (b64) and row reads (b128) both conflict-free
 constexpr int kHalfWaves = 16;                    // FFT blocks per workgroup step (512 threads)
 constexpr int kFftThreads = 32 * kHalfWaves;
 
-__device__ float2 g_fft_tab[2048];                // [0,1024): TW[a][b] = W^(a*b);  [1024,2048): Hs[kB][kA]
+__device__ float4 g_fft_tab[1024];                // [0,512): TW pairs [a/2][b] = {W^(a*b), W^((a+1)*b)};  [512,1024): Hs pairs [kB/2][kA]
 
 __host__ __device__ constexpr int br5(int p) {
     return ((p & 1) << 4) | ((p & 2) << 2) | (p & 4) | ((p & 8) >> 2) | ((p & 16) >> 4);
@@ -62,14 +63,30 @@ __device__ constexpr float kS32[16] = {0.0f, 0.19509032201612826785f, 0.38268343
 __device__ __forceinline__ v2f swap(v2f v) { return __builtin_shufflevector(v, v, 1, 0); }
 __device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-// a * w, w = (wr, wi)
+// a * w and a * conj(w), w = (wr, wi) a run-time value: 2 packed instructions, swap and sign in the modifiers
 __device__ __forceinline__ v2f cmul(v2f a, v2f w) {
-    const v2f t = a * (v2f){w.x, w.x};
-    return vfma(swap(a), (v2f){-w.y, w.y}, t);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
 }
 __device__ __forceinline__ v2f cmul_conj(v2f a, v2f w) {
-    const v2f t = a * (v2f){w.x, w.x};
-    return vfma(swap(a), (v2f){w.y, -w.y}, t);
+    v2f t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+
+// (a.x + b.y, a.y - b.x) and (a.x - b.y, a.y + b.x): a +- (b rotated by -+90 degrees) in one instruction
+__device__ __forceinline__ v2f add_swap_neghi(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ v2f add_swap_neglo(v2f a, v2f b) {
+    v2f r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // One decimation-in-time butterfly (a, b) -> (a + w b, a - w b), w = W_32^(+-m) (forward: exp(-j..)).
@@ -80,15 +97,14 @@ __device__ __forceinline__ void butterfly(v2f& a, v2f& b, const int m) {
         const v2f t = a;
         a = t + b;
         b = t - b;
-    } else if (m == 8) {  // w = -j (forward), +j (inverse)
-        const v2f bj = INV ? (v2f){-b.y, b.x} : (v2f){b.y, -b.x};
+    } else if (m == 8) {  // w = -j (forward), +j (inverse): b*w = (b.y, -b.x) / (-b.y, b.x)
         const v2f t = a;
-        a = t + bj;
-        b = t - bj;
+        if (INV) { a = add_swap_neglo(t, b); b = add_swap_neghi(t, b); }
+        else     { a = add_swap_neghi(t, b); b = add_swap_neglo(t, b); }
     } else if (m == 4 || m == 12) {
         // forward m=4: r(1-j)   m=12: -r(1+j);   inverse m=4: r(1+j)   m=12: -r(1-j)
         const bool minus_j = (m == 4) != INV;
-        const v2f s = minus_j ? (v2f){b.x + b.y, b.y - b.x} : (v2f){b.x - b.y, b.x + b.y};
+        const v2f s = minus_j ? add_swap_neghi(b, b) : add_swap_neglo(b, b);  // (bx+by, by-bx) : (bx-by, by+bx)
         const float g = (m == 4) ? r : -r;
         const v2f t = a;
         a = vfma(s, (v2f){g, g}, t);
@@ -136,22 +152,33 @@ __device__ __forceinline__ void load_syms32(const uint8_t* sym_f, int pos, uint4
     hi = p[1];
 }
 
+// A lane's row of 32 transposed values, 16 bytes at a time, into bit-reversed register order:
+// elements 2q, 2q+1 -> registers br5(2q), br5(2q)+16.
+__device__ __forceinline__ void load_row(v2f (&x)[32], const float4* row) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float4 v = row[q];
+        x[br5(2 * q)] = (v2f){v.x, v.y};
+        x[br5(2 * q) + 16] = (v2f){v.z, v.w};
+    }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __restrict__ sym, size_t sym_stride,
                                                              float2* __restrict__ iq, size_t iq_stride,
                                                              const float2* __restrict__ osc_tab, int channels,
                                                              int fields, int ch_per_group, int ch_groups) {
-    __shared__ float2 s_tw[1024];
-    __shared__ float2 s_h[1024];
-    __shared__ float2 s_x[kHalfWaves][32 * kRowPad];
+    __shared__ float4 s_tw[512];
+    __shared__ float4 s_h[512];
+    __shared__ __align__(16) float2 s_x[kHalfWaves][32 * kRowPad];
     const int tid = threadIdx.x;
     const int t = tid & 31;
     const int hw = tid >> 5;
 
-    for (int i = tid; i < 1024; i += kFftThreads) {
-        s_tw[i] = g_fft_tab[i];
-        s_h[i] = g_fft_tab[1024 + i];
+    {
+        s_tw[tid] = g_fft_tab[tid];
+        s_h[tid] = g_fft_tab[512 + tid];
     }
     __syncthreads();
 
@@ -179,10 +206,10 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     }
 
     float2* xs = s_x[hw];
-    const v2f* xsv = reinterpret_cast<const v2f*>(xs);
+    const float4* xrow = reinterpret_cast<const float4*>(xs + t * kRowPad);  // this lane's row after a transpose
     const uint8_t* xs8 = reinterpret_cast<const uint8_t*>(xs);
-    const v2f* tw = reinterpret_cast<const v2f*>(s_tw);
-    const v2f* hs = reinterpret_cast<const v2f*>(s_h);
+    const float4* tw = s_tw + t;
+    const float4* hs = s_h + t;
 
     uint4 s_lo, s_hi;
     load_syms32(sym + (size_t)c_lo * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
@@ -206,31 +233,39 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         // ---- forward pass 1 (over n2), twiddle, transpose
         fft32<false>(x);
 #pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const v2f v = k == 0 ? x[0] : cmul(x[k], tw[32 * k + t]);
-            *reinterpret_cast<v2f*>(&xs[k * kRowPad + t]) = v;
+        for (int k = 0; k < 32; k += 2) {
+            const float4 w = tw[16 * k];
+            const v2f v0 = k == 0 ? x[0] : cmul(x[k], (v2f){w.x, w.y});
+            const v2f v1 = cmul(x[k + 1], (v2f){w.z, w.w});
+            *reinterpret_cast<v2f*>(&xs[k * kRowPad + t]) = v0;
+            *reinterpret_cast<v2f*>(&xs[(k + 1) * kRowPad + t]) = v1;
         }
         wave_lds_sync();
-#pragma unroll
-        for (int p = 0; p < 32; ++p) x[p] = xsv[t * kRowPad + br5(p)];
+        load_row(x, xrow);
         wave_lds_sync();
 
         // ---- forward pass 2 (over n1), spectrum multiply; x[kB] = X[t + 32*kB] is the inverse's input kB
         fft32<false>(x);
         v2f y[32];
 #pragma unroll
-        for (int p = 0; p < 32; ++p) y[p] = cmul(x[br5(p)], hs[32 * br5(p) + t]);
+        for (int q = 0; q < 16; ++q) {  // spectrum rows kB = 2q, 2q+1 -> inverse input registers br5(2q), br5(2q)+16
+            const float4 h = hs[32 * q];
+            y[br5(2 * q)] = cmul(x[2 * q], (v2f){h.x, h.y});
+            y[br5(2 * q) + 16] = cmul(x[2 * q + 1], (v2f){h.z, h.w});
+        }
 
         // ---- inverse pass 1 (over kB), twiddle, transpose
         fft32<true>(y);
 #pragma unroll
-        for (int n = 0; n < 32; ++n) {
-            const v2f v = n == 0 ? y[0] : cmul_conj(y[n], tw[32 * n + t]);
-            *reinterpret_cast<v2f*>(&xs[n * kRowPad + t]) = v;
+        for (int n = 0; n < 32; n += 2) {
+            const float4 w = tw[16 * n];
+            const v2f v0 = n == 0 ? y[0] : cmul_conj(y[n], (v2f){w.x, w.y});
+            const v2f v1 = cmul_conj(y[n + 1], (v2f){w.z, w.w});
+            *reinterpret_cast<v2f*>(&xs[n * kRowPad + t]) = v0;
+            *reinterpret_cast<v2f*>(&xs[(n + 1) * kRowPad + t]) = v1;
         }
         wave_lds_sync();
-#pragma unroll
-        for (int p = 0; p < 32; ++p) y[p] = xsv[t * kRowPad + br5(p)];
+        load_row(y, xrow);
         wave_lds_sync();
 
         // ---- inverse pass 2 (over kA) -> y[t + 32*nA]; rows nA < 28 are free of circular wrap
@@ -262,14 +297,16 @@ hipError_t upload_fft_tables(const float* taps112) {
     static_assert((kFftBlocks - 1) * kFftValid + kFftN <= kFieldSyms + 820, "look-ahead must stay inside the sync-head copy");
     static_assert(kFftN - kFftValid >= 110, "overlap must cover the filter");
     static_assert((kFieldSyms - (kFftBlocks - 1) * kFftValid) % 32 == 0, "field end must fall on a 32-sample row");
-    std::vector<float> h(2 * 2048);
+    std::vector<float> h(4 * 1024);
     const double w0 = -2.0 * M_PI / kFftN;
+    // TW pairs: entry [a/2][b] holds W^(a*b) (a even) then W^((a+1)*b)
     for (int a = 0; a < 32; ++a)
         for (int b = 0; b < 32; ++b) {
-            h[2 * (32 * a + b)] = (float)std::cos(w0 * a * b);
-            h[2 * (32 * a + b) + 1] = (float)std::sin(w0 * a * b);
+            float* e = &h[4 * (32 * (a / 2) + b) + 2 * (a & 1)];
+            e[0] = (float)std::cos(w0 * a * b);
+            e[1] = (float)std::sin(w0 * a * b);
         }
-    // Hs[k] = conj(sum_n c[n] W^(n k)) / N, stored [kB][kA] with k = kA + 32 kB
+    // Hs[k] = conj(sum_n c[n] W^(n k)) / N with k = kA + 32 kB, stored as pairs [kB/2][kA]
     for (int k = 0; k < kFftN; ++k) {
         double re = 0, im = 0;
         for (int n = 0; n < 111; ++n) {
@@ -277,8 +314,9 @@ hipError_t upload_fft_tables(const float* taps112) {
             im += (double)taps112[n] * std::sin(w0 * n * k);
         }
         const int kA = k & 31, kB = k >> 5;
-        h[2 * (1024 + 32 * kB + kA)] = (float)(re / kFftN);
-        h[2 * (1024 + 32 * kB + kA) + 1] = (float)(-im / kFftN);
+        float* e = &h[4 * (512 + 32 * (kB / 2) + kA) + 2 * (kB & 1)];
+        e[0] = (float)(re / kFftN);
+        e[1] = (float)(-im / kFftN);
     }
     return hipMemcpyToSymbol(HIP_SYMBOL(g_fft_tab), h.data(), sizeof(float) * h.size());
 }
