@@ -26,9 +26,13 @@
 // reference's exact fp32 recursion (offset.h:35-41), so a task (block, field, channel group) needs no
 // history and the grid is a flat list of equal tasks.
 #include "kernels.h"
+#ifndef ATSC_ABLATE
+#define ATSC_ABLATE 0
+#endif
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace atsc_k {
@@ -39,6 +43,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 constexpr int kRowPad = 34;                       // LDS row stride (complex) of a 32x32 transpose: 16-byte aligned rows, column
                                                   // writes (b64) and row reads (b128) both conflict-free
+constexpr int kRowsLast = (kFieldSyms - (kFftBlocks - 1) * kFftValid) / 32;  // 18
 constexpr int kHalfWaves = 16;                    // FFT blocks per workgroup step (512 threads)
 constexpr int kFftThreads = 32 * kHalfWaves;
 
@@ -120,16 +125,26 @@ __device__ __forceinline__ void butterfly(v2f& a, v2f& b, const int m) {
 }
 
 // 32-point DIT FFT in registers: x[p] holds input element br5(p); on return x[k] holds output element k.
-template <bool INV>
-__device__ __forceinline__ void fft32(v2f (&x)[32]) {
+// `done(k)` is called as soon as outputs k and k+16 are final, so a caller can stream them out.
+template <bool INV, typename F>
+__device__ __forceinline__ void fft32(v2f (&x)[32], F done) {
 #pragma unroll
-    for (int half = 1; half < 32; half <<= 1) {
+    for (int half = 1; half < 16; half <<= 1) {
 #pragma unroll
         for (int g = 0; g < 32; g += 2 * half) {
 #pragma unroll
             for (int i = 0; i < half; ++i) butterfly<INV>(x[g + i], x[g + i + half], i * (16 / half));
         }
     }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        butterfly<INV>(x[i], x[i + 16], i);
+        done(i);
+    }
+}
+template <bool INV>
+__device__ __forceinline__ void fft32(v2f (&x)[32]) {
+    fft32<INV>(x, [](int) {});
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -163,6 +178,19 @@ __device__ __forceinline__ void load_row(v2f (&x)[32], const float4* row) {
     }
 }
 
+#if ATSC_ABLATE & 8
+#define TABREAD(e) make_float4(0.5f, 0.25f, 0.125f, 0.75f)
+#else
+#define TABREAD(e) (e)
+#endif
+#if ATSC_ABLATE & 4
+#define LOADROW(x, row) do { } while (0)
+#define STOREEL(x, k, v0, v1) do { x[k] = v0; x[k + 1] = v1; } while (0)
+#else
+#define LOADROW(x, row) load_row(x, row)
+#define STOREEL(x, k, v0, v1) do { *reinterpret_cast<v2f*>(&xs[(k) * kRowPad + t]) = v0; *reinterpret_cast<v2f*>(&xs[((k) + 1) * kRowPad + t]) = v1; } while (0)
+#endif
+
 }  // namespace
 
 __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __restrict__ sym, size_t sym_stride,
@@ -192,7 +220,6 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     const int c_lo = cg * ch_per_group, c_hi = min(channels, c_lo + ch_per_group);
 
     const int base = b * kFftValid;                       // first sample / first output of the block
-    const int rows_valid = min(kFftValid, kFieldSyms - base) >> 5;  // output rows of 32 that exist (28, or 18 at the end)
 
     // oscillator slice of the block, in the register order of the first transform: o[p] = T_f[base + t + 32*br5(p)]
     v2f o[32];
@@ -214,13 +241,22 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     uint4 s_lo, s_hi;
     load_syms32(sym + (size_t)c_lo * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
 
+    // Every load issued so far is complete before the loop is entered: the in-order vmcnt wait for the symbol
+    // prefetch at the top of an iteration then never has to cover the previous iteration's IQ stores.
+#pragma unroll
+    for (int p = 0; p < 32; ++p) asm volatile("" ::"v"(o[p]));
+    asm volatile("" ::"v"(s_lo.x), "v"(s_lo.y), "v"(s_lo.z), "v"(s_lo.w), "v"(s_hi.x), "v"(s_hi.y), "v"(s_hi.z), "v"(s_hi.w));
+
+    // The loop body exists twice, for full blocks (28 output rows) and for the last block of a field (18), so that
+    // the number of stores per iteration is a compile-time constant and the symbol-prefetch wait is an exact vmcnt(N).
+    auto run = [&](auto rows_tag) {
+    constexpr int kRows = decltype(rows_tag)::value;
     for (int c = c_lo; c < c_hi; ++c) {
         // ---- symbols: 32 consecutive bytes per lane -> LDS -> byte t + 32*j per lane
         reinterpret_cast<uint4*>(xs)[2 * t] = s_lo;
         reinterpret_cast<uint4*>(xs)[2 * t + 1] = s_hi;
         wave_lds_sync();
-        if (c + 1 < c_hi)
-            load_syms32(sym + (size_t)(c + 1) * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
+        load_syms32(sym + (size_t)min(c + 1, c_hi - 1) * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
 
         v2f x[32];
 #pragma unroll
@@ -234,14 +270,13 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         fft32<false>(x);
 #pragma unroll
         for (int k = 0; k < 32; k += 2) {
-            const float4 w = tw[16 * k];
+            const float4 w = TABREAD(tw[16 * k]);
             const v2f v0 = k == 0 ? x[0] : cmul(x[k], (v2f){w.x, w.y});
             const v2f v1 = cmul(x[k + 1], (v2f){w.z, w.w});
-            *reinterpret_cast<v2f*>(&xs[k * kRowPad + t]) = v0;
-            *reinterpret_cast<v2f*>(&xs[(k + 1) * kRowPad + t]) = v1;
+            STOREEL(x, k, v0, v1);
         }
         wave_lds_sync();
-        load_row(x, xrow);
+        LOADROW(x, xrow);
         wave_lds_sync();
 
         // ---- forward pass 2 (over n1), spectrum multiply; x[kB] = X[t + 32*kB] is the inverse's input kB
@@ -249,7 +284,7 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         v2f y[32];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {  // spectrum rows kB = 2q, 2q+1 -> inverse input registers br5(2q), br5(2q)+16
-            const float4 h = hs[32 * q];
+            const float4 h = TABREAD(hs[32 * q]);
             y[br5(2 * q)] = cmul(x[2 * q], (v2f){h.x, h.y});
             y[br5(2 * q) + 16] = cmul(x[2 * q + 1], (v2f){h.z, h.w});
         }
@@ -258,23 +293,39 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         fft32<true>(y);
 #pragma unroll
         for (int n = 0; n < 32; n += 2) {
-            const float4 w = tw[16 * n];
+            const float4 w = TABREAD(tw[16 * n]);
             const v2f v0 = n == 0 ? y[0] : cmul_conj(y[n], (v2f){w.x, w.y});
             const v2f v1 = cmul_conj(y[n + 1], (v2f){w.z, w.w});
-            *reinterpret_cast<v2f*>(&xs[n * kRowPad + t]) = v0;
-            *reinterpret_cast<v2f*>(&xs[(n + 1) * kRowPad + t]) = v1;
+            STOREEL(y, n, v0, v1);
         }
         wave_lds_sync();
-        load_row(y, xrow);
+        LOADROW(y, xrow);
         wave_lds_sync();
 
         // ---- inverse pass 2 (over kA) -> y[t + 32*nA]; rows nA < 28 are free of circular wrap
-        fft32<true>(y);
         float2* dst = iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + base + t;
+#if ATSC_ABLATE == 0
+        // rows leave as soon as the last butterfly stage has produced them: the stores drain under the remaining math
+        fft32<true>(y, [&](int i) {
+            if (i < kRows) dst[32 * i] = make_float2(y[i].x, y[i].y);
+            if (i + 16 < kRows) dst[32 * (i + 16)] = make_float2(y[i + 16].x, y[i + 16].y);
+        });
+#else
+        fft32<true>(y);
+#endif
+#if ATSC_ABLATE & 1
+#pragma unroll
+        for (int n = 0; n < kFftValid / 32; ++n) asm volatile("" ::"v"(y[n]));
+        if (y[0].x == 123.456f) dst[0] = make_float2(y[1].x, y[2].y);
+#elif ATSC_ABLATE & 2
 #pragma unroll
         for (int n = 0; n < kFftValid / 32; ++n)
-            if (n < rows_valid) dst[32 * n] = make_float2(y[n].x, y[n].y);
+            if (n < kRows) __builtin_nontemporal_store(y[n], reinterpret_cast<v2f*>(dst + 32 * n));
+#endif
     }
+    };
+    if (b != kFftBlocks - 1) run(std::integral_constant<int, kFftValid / 32>{});
+    else run(std::integral_constant<int, kRowsLast>{});
 }
 
 // Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41)
