@@ -153,7 +153,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     // oscillator state (double-buffered), T_0 and the per-field rotation
     for (int i = 0; i < 2; ++i) TRY_OR_FREE(hipMalloc(&e->d_osc[i], sizeof(float2) * kPaddedSyms));
     TRY_OR_FREE(hipMemcpy(e->d_osc[0], e->tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice));
-    TRY_OR_FREE(hipMalloc(&e->d_osc_tab, sizeof(float2) * kPaddedSyms * F));
+    TRY_OR_FREE(hipMalloc(&e->d_osc_tab, sizeof(float2) * (kPaddedSyms * F + kOscTabSlack)));
     e->scale = make_float2(e->tab.scale[0], e->tab.scale[1]);
 
     if (cfg->flags & ATSC_HIP_FLAG_TIMING) {

@@ -191,12 +191,81 @@ __device__ __forceinline__ void load_row(v2f (&x)[32], const float4* row) {
 #define STOREEL(x, k, v0, v1) do { *reinterpret_cast<v2f*>(&xs[(k) * kRowPad + t]) = v0; *reinterpret_cast<v2f*>(&xs[((k) + 1) * kRowPad + t]) = v1; } while (0)
 #endif
 
+
+
+// ---- phases of one 1024-point block (all on the 32 lanes that own it; `xs` is the block's LDS transpose buffer)
+
+// symbols: 32 consecutive bytes per lane -> LDS
+__device__ __forceinline__ void stage_syms(float2* xs, int t, const uint4& lo, const uint4& hi) {
+    reinterpret_cast<uint4*>(xs)[2 * t] = lo;
+    reinterpret_cast<uint4*>(xs)[2 * t + 1] = hi;
+}
+// byte t + 32*j per lane, level, times the oscillator: x * T as two single-rounded products (offset.h:24-31)
+__device__ __forceinline__ void mix(v2f (&x)[32], const float2* xs, int t, const v2f (&o)[32]) {
+    const uint8_t* xs8 = reinterpret_cast<const uint8_t*>(xs);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+        const float lv = level_of_byte(xs8[t + 32 * br5(p)]);
+        x[p] = o[p] * (v2f){lv, lv};
+    }
+}
+// transform over the registers, twiddle W^(+-t*k), write column t of the transpose, then start reading row t back
+template <bool INV>
+__device__ __forceinline__ void pass1(v2f (&x)[32], float2* xs, int t, const float4* tw) {
+    fft32<INV>(x);
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) {
+        const float4 w = TABREAD(tw[16 * k]);
+        const v2f w0 = (v2f){w.x, w.y}, w1 = (v2f){w.z, w.w};
+        const v2f v0 = k == 0 ? x[0] : (INV ? cmul_conj(x[k], w0) : cmul(x[k], w0));
+        const v2f v1 = INV ? cmul_conj(x[k + 1], w1) : cmul(x[k + 1], w1);
+        STOREEL(x, k, v0, v1);
+    }
+    wave_lds_sync();
+    LOADROW(x, reinterpret_cast<const float4*>(xs + t * kRowPad));
+    wave_lds_sync();
+}
+// forward pass 2 (over n1) and the spectrum multiply; x[kB] = X[t + 32*kB] becomes the inverse's input register br5(kB)
+__device__ __forceinline__ void pass2_spectrum(v2f (&x)[32], const float4* hs) {
+    fft32<false>(x);
+    v2f y[32];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float4 h = TABREAD(hs[32 * q]);
+        y[br5(2 * q)] = cmul(x[2 * q], (v2f){h.x, h.y});
+        y[br5(2 * q) + 16] = cmul(x[2 * q + 1], (v2f){h.z, h.w});
+    }
+#pragma unroll
+    for (int p = 0; p < 32; ++p) x[p] = y[p];
+}
+// inverse pass 2 (over kA) -> y[t + 32*nA]; rows nA < 28 are free of circular wrap.  Rows leave as soon as the last
+// butterfly stage has produced them.  dst_lo serves rows 0..17, dst_hi rows 18..27 (a trash area for the last block
+// of a field, which has only 18 rows): always 28 stores, so every vmcnt wait in the loop is exact.
+__device__ __forceinline__ void pass4_store(v2f (&y)[32], float2* dst_lo, float2* dst_hi) {
+#if ATSC_ABLATE & 1
+    fft32<true>(y);
+#pragma unroll
+    for (int n = 0; n < kFftValid / 32; ++n) asm volatile("" ::"v"(y[n]));
+    if (y[0].x == 123.456f) dst_lo[0] = make_float2(y[1].x, y[2].y);
+#else
+    fft32<true>(y, [&](int i) {
+        dst_lo[32 * i] = make_float2(y[i].x, y[i].y);
+        if (i + 16 < kRowsLast) dst_lo[32 * (i + 16)] = make_float2(y[i + 16].x, y[i + 16].y);
+        else if (i + 16 < kFftValid / 32) dst_hi[32 * (i + 16)] = make_float2(y[i + 16].x, y[i + 16].y);
+    });
+#endif
+}
+
 }  // namespace
 
+// One task = (FFT block b, field f, channel group): a half-wave walks the group's channels two at a time.  The two
+// streams A and B share the oscillator registers and the LDS buffer and are interleaved phase by phase, so that the
+// LDS round trip of one stream's transpose and the drain of its IQ stores run under the other stream's butterflies
+// (LDS operations of a wave execute in program order, which is all the ordering the shared buffer needs).
 __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __restrict__ sym, size_t sym_stride,
                                                              float2* __restrict__ iq, size_t iq_stride,
-                                                             const float2* __restrict__ osc_tab, int channels,
-                                                             int fields, int ch_per_group, int ch_groups) {
+                                                             const float2* __restrict__ osc_tab, float2* __restrict__ trash,
+                                                             int channels, int fields, int ch_per_group, int ch_groups) {
     __shared__ float4 s_tw[512];
     __shared__ float4 s_h[512];
     __shared__ __align__(16) float2 s_x[kHalfWaves][32 * kRowPad];
@@ -204,13 +273,10 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     const int t = tid & 31;
     const int hw = tid >> 5;
 
-    {
-        s_tw[tid] = g_fft_tab[tid];
-        s_h[tid] = g_fft_tab[512 + tid];
-    }
+    s_tw[tid] = g_fft_tab[tid];
+    s_h[tid] = g_fft_tab[512 + tid];
     __syncthreads();
 
-    // task = (FFT block b, field f, channel group cg)
     const long task = (long)blockIdx.x * kHalfWaves + hw;
     const int b = (int)(task % kFftBlocks);
     const long g = task / kFftBlocks;
@@ -218,8 +284,7 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     const int f = (int)(g / ch_groups);
     if (f >= fields) return;
     const int c_lo = cg * ch_per_group, c_hi = min(channels, c_lo + ch_per_group);
-
-    const int base = b * kFftValid;                       // first sample / first output of the block
+    const int base = b * kFftValid;  // first sample / first output of the block
 
     // oscillator slice of the block, in the register order of the first transform: o[p] = T_f[base + t + 32*br5(p)]
     v2f o[32];
@@ -233,99 +298,55 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     }
 
     float2* xs = s_x[hw];
-    const float4* xrow = reinterpret_cast<const float4*>(xs + t * kRowPad);  // this lane's row after a transpose
-    const uint8_t* xs8 = reinterpret_cast<const uint8_t*>(xs);
     const float4* tw = s_tw + t;
     const float4* hs = s_h + t;
+    const uint8_t* sym_f = sym + (size_t)f * kFieldSyms;
+    float2* iq_f = iq + (size_t)f * kFieldSyms + base + t;
+    float2* trash_t = trash + t;
+    const bool full_block = b != kFftBlocks - 1;
 
-    uint4 s_lo, s_hi;
-    load_syms32(sym + (size_t)c_lo * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
+    // stream B of the last pair repeats stream A when the group has an odd number of channels; its rows go to trash
+    uint4 a_lo, a_hi, b_lo, b_hi;
+    load_syms32(sym_f + (size_t)c_lo * sym_stride, base + 32 * t, a_lo, a_hi);
+    load_syms32(sym_f + (size_t)min(c_lo + 1, c_hi - 1) * sym_stride, base + 32 * t, b_lo, b_hi);
 
     // Every load issued so far is complete before the loop is entered: the in-order vmcnt wait for the symbol
     // prefetch at the top of an iteration then never has to cover the previous iteration's IQ stores.
 #pragma unroll
     for (int p = 0; p < 32; ++p) asm volatile("" ::"v"(o[p]));
-    asm volatile("" ::"v"(s_lo.x), "v"(s_lo.y), "v"(s_lo.z), "v"(s_lo.w), "v"(s_hi.x), "v"(s_hi.y), "v"(s_hi.z), "v"(s_hi.w));
+    asm volatile("" ::"v"(a_lo.x), "v"(a_lo.y), "v"(a_lo.z), "v"(a_lo.w), "v"(a_hi.x), "v"(a_hi.y), "v"(a_hi.z), "v"(a_hi.w));
+    asm volatile("" ::"v"(b_lo.x), "v"(b_lo.y), "v"(b_lo.z), "v"(b_lo.w), "v"(b_hi.x), "v"(b_hi.y), "v"(b_hi.z), "v"(b_hi.w));
 
-    // The loop body exists twice, for full blocks (28 output rows) and for the last block of a field (18), so that
-    // the number of stores per iteration is a compile-time constant and the symbol-prefetch wait is an exact vmcnt(N).
-    auto run = [&](auto rows_tag) {
-    constexpr int kRows = decltype(rows_tag)::value;
-    for (int c = c_lo; c < c_hi; ++c) {
-        // ---- symbols: 32 consecutive bytes per lane -> LDS -> byte t + 32*j per lane
-        reinterpret_cast<uint4*>(xs)[2 * t] = s_lo;
-        reinterpret_cast<uint4*>(xs)[2 * t + 1] = s_hi;
+    for (int c = c_lo; c < c_hi; c += 2) {
+        v2f xa[32], xb[32];
+        // ---- symbols of both streams through LDS, next pair's symbols prefetched
+        stage_syms(xs, t, a_lo, a_hi);
         wave_lds_sync();
-        load_syms32(sym + (size_t)min(c + 1, c_hi - 1) * sym_stride + (size_t)f * kFieldSyms, base + 32 * t, s_lo, s_hi);
-
-        v2f x[32];
-#pragma unroll
-        for (int p = 0; p < 32; ++p) {
-            const float lv = level_of_byte(xs8[t + 32 * br5(p)]);
-            x[p] = o[p] * (v2f){lv, lv};  // x * T: two single-rounded products (offset.h:24-31)
+        mix(xa, xs, t, o);
+        wave_lds_sync();
+        stage_syms(xs, t, b_lo, b_hi);
+        wave_lds_sync();
+        mix(xb, xs, t, o);
+        wave_lds_sync();
+        {
+            const int ca = min(c + 2, c_hi - 1), cb = min(c + 3, c_hi - 1);
+            load_syms32(sym_f + (size_t)ca * sym_stride, base + 32 * t, a_lo, a_hi);
+            load_syms32(sym_f + (size_t)cb * sym_stride, base + 32 * t, b_lo, b_hi);
         }
-        wave_lds_sync();
-
-        // ---- forward pass 1 (over n2), twiddle, transpose
-        fft32<false>(x);
-#pragma unroll
-        for (int k = 0; k < 32; k += 2) {
-            const float4 w = TABREAD(tw[16 * k]);
-            const v2f v0 = k == 0 ? x[0] : cmul(x[k], (v2f){w.x, w.y});
-            const v2f v1 = cmul(x[k + 1], (v2f){w.z, w.w});
-            STOREEL(x, k, v0, v1);
-        }
-        wave_lds_sync();
-        LOADROW(x, xrow);
-        wave_lds_sync();
-
-        // ---- forward pass 2 (over n1), spectrum multiply; x[kB] = X[t + 32*kB] is the inverse's input kB
-        fft32<false>(x);
-        v2f y[32];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {  // spectrum rows kB = 2q, 2q+1 -> inverse input registers br5(2q), br5(2q)+16
-            const float4 h = TABREAD(hs[32 * q]);
-            y[br5(2 * q)] = cmul(x[2 * q], (v2f){h.x, h.y});
-            y[br5(2 * q) + 16] = cmul(x[2 * q + 1], (v2f){h.z, h.w});
-        }
-
-        // ---- inverse pass 1 (over kB), twiddle, transpose
-        fft32<true>(y);
-#pragma unroll
-        for (int n = 0; n < 32; n += 2) {
-            const float4 w = TABREAD(tw[16 * n]);
-            const v2f v0 = n == 0 ? y[0] : cmul_conj(y[n], (v2f){w.x, w.y});
-            const v2f v1 = cmul_conj(y[n + 1], (v2f){w.z, w.w});
-            STOREEL(y, n, v0, v1);
-        }
-        wave_lds_sync();
-        LOADROW(y, xrow);
-        wave_lds_sync();
-
-        // ---- inverse pass 2 (over kA) -> y[t + 32*nA]; rows nA < 28 are free of circular wrap
-        float2* dst = iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + base + t;
-#if ATSC_ABLATE == 0
-        // rows leave as soon as the last butterfly stage has produced them: the stores drain under the remaining math
-        fft32<true>(y, [&](int i) {
-            if (i < kRows) dst[32 * i] = make_float2(y[i].x, y[i].y);
-            if (i + 16 < kRows) dst[32 * (i + 16)] = make_float2(y[i + 16].x, y[i + 16].y);
-        });
-#else
-        fft32<true>(y);
-#endif
-#if ATSC_ABLATE & 1
-#pragma unroll
-        for (int n = 0; n < kFftValid / 32; ++n) asm volatile("" ::"v"(y[n]));
-        if (y[0].x == 123.456f) dst[0] = make_float2(y[1].x, y[2].y);
-#elif ATSC_ABLATE & 2
-#pragma unroll
-        for (int n = 0; n < kFftValid / 32; ++n)
-            if (n < kRows) __builtin_nontemporal_store(y[n], reinterpret_cast<v2f*>(dst + 32 * n));
-#endif
+        // ---- forward: A's transpose is in flight while B's first pass runs, and so on
+        pass1<false>(xa, xs, t, tw);
+        pass1<false>(xb, xs, t, tw);
+        pass2_spectrum(xa, hs);
+        pass1<true>(xa, xs, t, tw);
+        pass2_spectrum(xb, hs);
+        pass1<true>(xb, xs, t, tw);
+        // ---- inverse pass 2 and the stores
+        const bool b_real = c + 1 < c_hi;
+        float2* da = iq_f + (size_t)c * iq_stride;
+        float2* db = b_real ? iq_f + (size_t)(c + 1) * iq_stride : trash_t;
+        pass4_store(xa, da, full_block ? da : trash_t);
+        pass4_store(xb, db, full_block ? db : trash_t);
     }
-    };
-    if (b != kFftBlocks - 1) run(std::integral_constant<int, kFftValid / 32>{});
-    else run(std::integral_constant<int, kRowsLast>{});
 }
 
 // Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41)
@@ -381,7 +402,8 @@ void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, 
     const int ch_groups = (channels + ch_per_group - 1) / ch_per_group;
     const long tasks = (long)kFftBlocks * ch_groups * fields;
     const unsigned grid = (unsigned)((tasks + kHalfWaves - 1) / kHalfWaves);
-    hipLaunchKernelGGL(k_mix_fir_fft, dim3(grid), dim3(kFftThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_tab,
+    float2* trash = osc_tab + (size_t)fields * kPaddedSyms;  // 1024 complex behind the table (see kOscTabSlack)
+    hipLaunchKernelGGL(k_mix_fir_fft, dim3(grid), dim3(kFftThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_tab, trash,
                        channels, fields, ch_per_group, ch_groups);
 }
 

@@ -32,6 +32,7 @@ constexpr int kFirCols = (kFirTile + 112) / kFirR; // 270 staged columns of 8 sa
 constexpr int kFftN = 1024;
 constexpr int kFftValid = 896;
 constexpr int kFftBlocks = (kFieldSyms + kFftValid - 1) / kFftValid;  // 291
+constexpr int kOscTabSlack = 1024;  // complex64 entries behind the oscillator table that absorb stores of rows that do not exist
 
 struct DeviceTables {
     const uint32_t* prbs188;   // 58656 B, TS-field layout, dword view
@@ -65,7 +66,7 @@ void launch_mix_fir(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, floa
                     const float2* osc_in, float2* osc_out, float2 scale, int channels, int fields);
 void launch_osc_advance(hipStream_t s, const float2* osc_in, float2* osc_out, float2 scale, unsigned steps);
 hipError_t upload_taps(const float* taps112);
-// Overlap-save FFT form of the same stage (fir_fft.hip).  osc_tab: fields x 261248 complex64 scratch that receives
+// Overlap-save FFT form of the same stage (fir_fft.hip).  osc_tab: (fields x 261248 + kOscTabSlack) complex64 scratch that receives
 // T_f for every field of the batch; osc_out receives the state after the batch.
 void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
                         const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int channels, int fields);
