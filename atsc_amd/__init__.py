@@ -24,9 +24,10 @@ INTERLEAVER_TAIL = 10608
 SYMBOL_RATE = 4500000.0 / 286 * 684  # 10.762238 MHz, one real-time channel
 
 FLAG_TIMING = 1
-(STAGE_RAND_RS, STAGE_INTERLEAVE, STAGE_TRELLIS_PAR, STAGE_TRELLIS_SCAN, STAGE_TRELLIS_MAP, STAGE_MIX_FIR,
- STAGE_STATE, NSTAGES) = range(8)
-STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trellis_map", "mix_fir", "save_state")
+(STAGE_RAND_RS, STAGE_INTERLEAVE, STAGE_TRELLIS_PAR, STAGE_TRELLIS_SCAN, STAGE_TRELLIS_MAP, STAGE_OSC, STAGE_MIX_FIR,
+ STAGE_STATE, NSTAGES) = range(9)
+STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trellis_map", "osc_table", "mix_fir",
+               "save_state")
 
 # every symbol include/atsc_hip.h declares
 EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_encode_batch",

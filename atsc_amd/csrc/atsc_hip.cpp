@@ -128,7 +128,6 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     e->dtab.prbs188 = reinterpret_cast<const uint32_t*>(tb + off_prbs);
     e->dtab.rs_rows = reinterpret_cast<const uint4*>(tb + off_rows);
     e->dtab.fsync = tb + off_fs;
-    TRY_OR_FREE(upload_taps(e->tab.taps));
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
 
     // per-channel working buffers
@@ -226,18 +225,17 @@ int run_back(atsc_hip_encoder* e, const uint4* carry_xor, int fields, uint8_t* d
 
 int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, void* d_iq, int fields, hipStream_t s) {
     const int C = e->cfg.channels;
-    mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
+    mark(e, s, ATSC_HIP_STAGE_OSC);
     const float2* oin = e->d_osc[e->osc_cur];
     float2* oout = e->d_osc[e->osc_cur ^ 1];
-    static const int variant = [] { const char* v = getenv("ATSC_FIR_VARIANT"); return v ? atoi(v) : 2; }();
-    if (d_iq && variant == 2)
-        launch_mix_fir_fft(s, d_sym, sym_stride, static_cast<float2*>(d_iq), (size_t)fields * kFieldSyms, oin, oout,
-                           e->d_osc_tab, e->scale, C, fields);
-    else if (d_iq)
-        launch_mix_fir(s, d_sym, sym_stride, static_cast<float2*>(d_iq), (size_t)fields * kFieldSyms, oin, oout, e->scale,
-                       C, fields);
-    else
+    if (d_iq) {
+        launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields);
+        mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
+        launch_mix_fir_fft(s, d_sym, sym_stride, static_cast<float2*>(d_iq), (size_t)fields * kFieldSyms, e->d_osc_tab, C,
+                           fields);
+    } else {
         launch_osc_advance(s, oin, oout, e->scale, (unsigned)fields);
+    }
     e->osc_cur ^= 1;
     return static_cast<int>(hipGetLastError());
 }

@@ -44,6 +44,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kRowPad = 34;                       // LDS row stride (complex) of a 32x32 transpose: 16-byte aligned rows, column
                                                   // writes (b64) and row reads (b128) both conflict-free
 constexpr int kRowsLast = (kFieldSyms - (kFftBlocks - 1) * kFftValid) / 32;  // 18
+constexpr int kTwAhead = 3;                       // twiddle pairs (16 B each) read ahead of use
 constexpr int kHalfWaves = 16;                    // FFT blocks per workgroup step (512 threads)
 constexpr int kFftThreads = 32 * kHalfWaves;
 
@@ -212,18 +213,27 @@ __device__ __forceinline__ void mix(v2f (&x)[32], const float2* xs, int t, const
 // transform over the registers, twiddle W^(+-t*k), write column t of the transpose, then start reading row t back
 template <bool INV>
 __device__ __forceinline__ void pass1(v2f (&x)[32], float2* xs, int t, const float4* tw) {
+    __builtin_amdgcn_sched_barrier(0);  // phases stay in program order: the other stream's transpose is in flight
     fft32<INV>(x);
+    __builtin_amdgcn_sched_barrier(0);
+    // twiddle table reads run kTwAhead pairs ahead of their use
+    float4 wq[kTwAhead];
+#pragma unroll
+    for (int d = 0; d < kTwAhead; ++d) wq[d] = TABREAD(tw[32 * d]);
 #pragma unroll
     for (int k = 0; k < 32; k += 2) {
-        const float4 w = TABREAD(tw[16 * k]);
+        const float4 w = wq[(k / 2) % kTwAhead];
+        if (k / 2 + kTwAhead < 16) wq[(k / 2) % kTwAhead] = TABREAD(tw[16 * (k + 2 * kTwAhead)]);
         const v2f w0 = (v2f){w.x, w.y}, w1 = (v2f){w.z, w.w};
         const v2f v0 = k == 0 ? x[0] : (INV ? cmul_conj(x[k], w0) : cmul(x[k], w0));
         const v2f v1 = INV ? cmul_conj(x[k + 1], w1) : cmul(x[k + 1], w1);
         STOREEL(x, k, v0, v1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_sync();
     LOADROW(x, reinterpret_cast<const float4*>(xs + t * kRowPad));
     wave_lds_sync();
+    __builtin_amdgcn_sched_barrier(0);
 }
 // forward pass 2 (over n1) and the spectrum multiply; x[kB] = X[t + 32*kB] becomes the inverse's input register br5(kB)
 __device__ __forceinline__ void pass2_spectrum(v2f (&x)[32], const float4* hs) {
@@ -342,8 +352,14 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         pass1<true>(xb, xs, t, tw);
         // ---- inverse pass 2 and the stores
         const bool b_real = c + 1 < c_hi;
+#if ATSC_ABLATE & 16
+        float2* da = trash_t;
+        float2* db = trash_t;
+        (void)b_real;
+#else
         float2* da = iq_f + (size_t)c * iq_stride;
         float2* db = b_real ? iq_f + (size_t)(c + 1) * iq_stride : trash_t;
+#endif
         pass4_store(xa, da, full_block ? da : trash_t);
         pass4_store(xb, db, full_block ? db : trash_t);
     }
@@ -393,16 +409,20 @@ hipError_t upload_fft_tables(const float* taps112) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_fft_tab), h.data(), sizeof(float) * h.size());
 }
 
-void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
-                        const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int channels, int fields) {
+void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields) {
     hipLaunchKernelGGL(k_osc_table, dim3((kPaddedSyms + 255) / 256), dim3(256), 0, s, osc_in, osc_tab, osc_out, scale,
                        fields);
+}
+
+void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
+                        float2* osc_tab, int channels, int fields) {
+    // tasks of 8 channels: small enough that the flat task list balances over 256 CUs (>= 36 rounds at 64 x 64)
     static const int cpg_env = [] { const char* e = getenv("ATSC_FIR_CH_PER_TASK"); return e ? atoi(e) : 8; }();
     const int ch_per_group = channels < cpg_env ? channels : cpg_env;
     const int ch_groups = (channels + ch_per_group - 1) / ch_per_group;
     const long tasks = (long)kFftBlocks * ch_groups * fields;
     const unsigned grid = (unsigned)((tasks + kHalfWaves - 1) / kHalfWaves);
-    float2* trash = osc_tab + (size_t)fields * kPaddedSyms;  // 1024 complex behind the table (see kOscTabSlack)
+    float2* trash = osc_tab + (size_t)fields * kPaddedSyms;  // kOscTabSlack complex behind the table
     hipLaunchKernelGGL(k_mix_fir_fft, dim3(grid), dim3(kFftThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_tab, trash,
                        channels, fields, ch_per_group, ch_groups);
 }

@@ -21,13 +21,6 @@ constexpr int kParts = 26;                         // trellis "parts" per field:
 constexpr int kPartGroups = 207;                   // 12-byte groups (byte-times) per part
 constexpr int kTaps = 112;
 
-// FIR tiling.
-constexpr int kFirR = 8;                           // consecutive outputs per lane
-constexpr int kFirThreads = 256;
-constexpr int kFirTile = kFirThreads * kFirR;      // 2048 outputs per block iteration
-constexpr int kFirTiles = (kFieldSyms + kFirTile - 1) / kFirTile;  // 128
-constexpr int kFirCols = (kFirTile + 112) / kFirR; // 270 staged columns of 8 samples
-
 // Overlap-save FIR geometry (fir_fft.hip): 1024-point blocks advancing by 896 outputs.
 constexpr int kFftN = 1024;
 constexpr int kFftValid = 896;
@@ -61,15 +54,14 @@ void launch_span_parity(hipStream_t s, const Buffers& b, uint4* d_out, int chann
 void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride,
                         int channels, int fields, uint64_t field_base);
 void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields);
-// Mixer + FIR.  osc_in/osc_out: 261248 complex64 each (double-buffered state); scale = per-field rotation.
-void launch_mix_fir(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride /*complex*/,
-                    const float2* osc_in, float2* osc_out, float2 scale, int channels, int fields);
+// Oscillator state alone advanced by `steps` fields (offset.h:35-41).  261248 complex64 each.
 void launch_osc_advance(hipStream_t s, const float2* osc_in, float2* osc_out, float2 scale, unsigned steps);
-hipError_t upload_taps(const float* taps112);
-// Overlap-save FFT form of the same stage (fir_fft.hip).  osc_tab: (fields x 261248 + kOscTabSlack) complex64 scratch that receives
-// T_f for every field of the batch; osc_out receives the state after the batch.
+// Mixer + FIR (fir_fft.hip).  osc_tab: (fields x 261248 + kOscTabSlack) complex64 scratch.
+// launch_osc_table fills osc_tab[f] = T_(f0+f) for the batch from the state osc_in and leaves the state after the
+// batch in osc_out (offset.h:35-41); launch_mix_fir_fft then produces the IQ of every (channel, field).
+void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields);
 void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
-                        const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int channels, int fields);
+                        float2* osc_tab, int channels, int fields);
 hipError_t upload_fft_tables(const float* taps112);
 
 }  // namespace atsc_k

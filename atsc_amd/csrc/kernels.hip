@@ -5,19 +5,14 @@
 //   k_trellis_parity per-part GF(2) parities of the 12 precoders/trellis encoders  reference: trellis.h:10-51,240-242
 //   k_trellis_scan   exclusive XOR scan of the parities -> carry entering every part
 //   k_trellis_map    precoder + trellis + 8-level map + segment/field sync -> u8 symbols   reference: trellis.h:121-499,549-576, field_sync.h:12-26
-//   k_mix_fir        pilot/offset mixer + 112-tap RRC FIR -> complex64          reference: offset.h:11-45, filter.h:9-69
+//   (k_mix_fir_fft   pilot/offset mixer + 112-tap RRC FIR -> complex64: fir_fft.hip)
 //   k_osc_advance    oscillator table advance by n fields                        reference: offset.h:35-41
 //   k_save_state     end-of-batch history (interleaver tail, last group)
 //
 // All byte/bit stages are bit-exact restatements of the closed forms in SURVEY.md Appendix A; the float
-// stage follows the reference's rounding for the oscillator recursion and sums the FIR in tap order.
+// stage (fir_fft.hip) follows the reference's rounding for the oscillator recursion.
 #include "kernels.h"
-#ifndef ATSC_ABLATE
-#define ATSC_ABLATE 0
-#endif
 
-#include <cstdlib>
-#include <utility>
 
 namespace atsc_k {
 
@@ -421,448 +416,12 @@ void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields
 }
 
 // ======================================================================================= K5 mixer + FIR
-// y[i] = sum_k c[k] * x[i+k] * T_f[i+k], x = 2v - 7 + 1.25 real, T_f complex (offset.h, filter.h).
-// VALU-bound (446 flop/sample): each lane keeps kFirR consecutive complex outputs in registers and
-// slides over kFirR+110 staged samples, one ds_read_b64 per sample and up to kFirR packed FMAs
-// (v_pk_fma_f32: re,im in one instruction, tap broadcast from an SGPR).  Staged samples live in LDS
-// transposed by (sample mod 8) so that both the staging writes and the sliding reads are
-// conflict-free.  The oscillator slice of the tile stays in registers for the whole kernel: a block
-// walks fields f_lo..f_hi of its channels and advances its slice by the reference's fp32 recursion
-// (re = fma(cr,er,-(ci*ei)), im = fma(ci,er,cr*ei)) once per field, so no per-field table is ever
-// written to HBM.  Symbols of the next (channel, field) are prefetched into registers while the
-// current tile is being filtered.
-// The 111 taps are symmetric (c[k] == c[110-k] bit-for-bit, checked on the host) and c[111] == 0, so the
-// 56 unique values live in 28 aligned SGPR pairs for the whole kernel; op_sel picks the half of a pair
-// that is broadcast to both lanes of the packed FMA.
-__constant__ unsigned long long c_tap_pairs[28];
-hipError_t upload_taps_ffa(const float* taps112);
-
-hipError_t upload_taps(const float* taps112) {
-    float pairs[56];
-    for (int k = 0; k < 56; ++k) pairs[k] = taps112[k];
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_tap_pairs), pairs, sizeof pairs);
-    return e != hipSuccess ? e : upload_taps_ffa(taps112);
-}
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-// acc += x * c[k] on (re, im) at once.  k is a compile-time constant after unrolling.
-__device__ __forceinline__ void fir_fma(v2f& acc, const v2f x, const unsigned long long (&tp)[28], const int k) {
-    const int u = k <= 55 ? k : 110 - k;
-    if (u & 1)
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "s"(tp[u >> 1]));
-    else
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "s"(tp[u >> 1]));
-}
+// lives in fir_fft.hip (overlap-save fast convolution)
 
 __device__ __forceinline__ float2 osc_step(float2 t, float2 sc) {
     const float t2 = __fmul_rn(t.y, sc.y);
     const float t3 = __fmul_rn(t.x, sc.y);
     return make_float2(__fmaf_rn(t.x, sc.x, -t2), __fmaf_rn(t.y, sc.x, t3));
-}
-
-struct SymRegs { uint32_t lo, hi; bool on; };
-
-// Symbols for 8 consecutive padded positions starting at pos (multiple of 8):
-// pos < 260416: the field; 260416 <= pos < 260416+112: copy of the field's sync head (field_sync.h:16);
-// beyond: never reaches a valid output (c[111] = 0), treated as 0.
-__device__ __forceinline__ SymRegs load_syms(const uint8_t* sym_f, int pos) {
-    SymRegs r{0u, 0u, false};
-    int src = -1;
-    if (pos < kFieldSyms) src = pos;
-    else if (pos < kFieldSyms + 112) src = pos - kFieldSyms;
-    if (src >= 0) {
-        const uint2 v = *reinterpret_cast<const uint2*>(sym_f + src);
-        r.lo = v.x; r.hi = v.y; r.on = true;
-    }
-    return r;
-}
-
-__device__ __forceinline__ float level_of(uint32_t w, int j) {
-    // 2v - 7 + 1.25 (signal.h:16): exact in fp32
-    return __fmaf_rn((float)((w >> (8 * j)) & 0xffu), 2.0f, -5.75f);
-}
-
-// 8 oscillator entries starting at pos (multiple of 8; the table length is a multiple of 8)
-__device__ __forceinline__ void load_osc8(const float2* osc, int pos, bool on, float2 (&t)[kFirR]) {
-    if (on && pos < kPaddedSyms) {
-        const float4* p = reinterpret_cast<const float4*>(osc + pos);
-#pragma unroll
-        for (int j = 0; j < kFirR / 2; ++j) {
-            const float4 v = p[j];
-            t[2 * j] = make_float2(v.x, v.y);
-            t[2 * j + 1] = make_float2(v.z, v.w);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < kFirR; ++j) t[j] = make_float2(0.f, 0.f);
-    }
-}
-
-constexpr int kFirDepth = 6;  // LDS reads in flight ahead of the FMAs that consume them
-constexpr int kFirSteps = kFirR + 110;
-
-// One step of the sliding window, fully resolved at compile time: sample J (already in the ring)
-// feeds the outputs r with tap k = J - r in 0..110, and the read of sample J + depth is issued.
-template <int J>
-__device__ __forceinline__ void fir_step(v2f (&acc)[kFirR], v2f (&ring)[kFirDepth], const v2f* xs,
-                                         const unsigned long long (&tp)[28]) {
-    const v2f x = ring[J % kFirDepth];
-    if constexpr (J + kFirDepth < kFirSteps) {
-        constexpr int jn = J + kFirDepth;
-        ring[J % kFirDepth] = xs[(jn % kFirR) * kFirCols + jn / kFirR];
-    }
-#pragma unroll
-    for (int r = 0; r < kFirR; ++r) {
-        const int k = J - r;
-        if (k >= 0 && k <= 110) fir_fma(acc[r], x, tp, k);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int... Js>
-__device__ __forceinline__ void fir_steps(v2f (&acc)[kFirR], v2f (&ring)[kFirDepth], const v2f* xs,
-                                          const unsigned long long (&tp)[28], std::integer_sequence<int, Js...>) {
-    (fir_step<Js>(acc, ring, xs, tp), ...);
-}
-template <int... Js>
-__device__ __forceinline__ void fir_prime(v2f (&ring)[kFirDepth], const v2f* xs, std::integer_sequence<int, Js...>) {
-    ((ring[Js] = xs[(Js % kFirR) * kFirCols + Js / kFirR]), ...);
-}
-
-__global__ __launch_bounds__(kFirThreads) void k_mix_fir(const uint8_t* __restrict__ sym, size_t sym_stride,
-                                                         float2* __restrict__ iq, size_t iq_stride,
-                                                         const float2* __restrict__ osc_in, float2* __restrict__ osc_out,
-                                                         float2 scale, int channels, int fields, int ch_per_group,
-                                                         int f_per_group) {
-    __shared__ float2 s_x[kFirR * kFirCols];  // 17280 B
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int tile = blockIdx.x;
-    const int c_lo = blockIdx.y * ch_per_group, c_hi = min(channels, c_lo + ch_per_group);
-    const int f_lo = blockIdx.z * f_per_group, f_hi = min(fields, f_lo + f_per_group);
-    const bool halo = tid < (kFirCols - kFirThreads);  // threads 0..13 also stage the 112-sample look-ahead
-    const int pos_main = tile * kFirTile + kFirR * tid;
-    const int pos_halo = (tile + 1) * kFirTile + kFirR * tid;
-
-    unsigned long long tp[28];
-#pragma unroll
-    for (int m = 0; m < 28; ++m) tp[m] = c_tap_pairs[m];
-
-    // oscillator slice -> registers, advanced to field f_lo
-    float2 tm[kFirR], th[kFirR];
-    load_osc8(osc_in, pos_main, true, tm);
-    load_osc8(osc_in, pos_halo, halo, th);
-    for (int n = 0; n < f_lo; ++n) {
-#pragma unroll
-        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
-    }
-
-    const int out0 = tile * kFirTile + wv * (64 * kFirR) + lane * kFirR;  // first output of this lane
-    const bool lane_on = out0 < kFieldSyms;                                 // 260416 - 127*2048 = 320 = 8*40
-
-    SymRegs sm, sh;
-    {
-        const uint8_t* sf = sym + (size_t)c_lo * sym_stride + (size_t)f_lo * kFieldSyms;
-        sm = load_syms(sf, pos_main);
-        sh = halo ? load_syms(sf, pos_halo) : SymRegs{0u, 0u, false};
-    }
-
-    for (int f = f_lo; f < f_hi; ++f) {
-        for (int c = c_lo; c < c_hi; ++c) {
-            // ---- stage current symbols x oscillator into LDS (transposed by sample mod 8)
-#pragma unroll
-            for (int j = 0; j < kFirR; ++j) {
-                const float x = sm.on ? level_of(j < 4 ? sm.lo : sm.hi, j & 3) : 0.0f;
-                s_x[j * kFirCols + tid] = make_float2(__fmul_rn(x, tm[j].x), __fmul_rn(x, tm[j].y));
-            }
-            if (halo) {
-#pragma unroll
-                for (int j = 0; j < kFirR; ++j) {
-                    const float x = sh.on ? level_of(j < 4 ? sh.lo : sh.hi, j & 3) : 0.0f;
-                    s_x[j * kFirCols + kFirThreads + tid] = make_float2(__fmul_rn(x, th[j].x), __fmul_rn(x, th[j].y));
-                }
-            }
-            __syncthreads();
-
-            // ---- prefetch the next (channel, field) symbols
-            {
-                int cn = c + 1, fn = f;
-                if (cn == c_hi) { cn = c_lo; fn = f + 1; }
-                if (fn < f_hi) {
-                    const uint8_t* sf = sym + (size_t)cn * sym_stride + (size_t)fn * kFieldSyms;
-                    sm = load_syms(sf, pos_main);
-                    if (halo) sh = load_syms(sf, pos_halo);
-                }
-            }
-
-            // ---- sliding-window FIR: sample j feeds outputs r = j-k; kFirDepth LDS reads stay in flight
-            v2f acc[kFirR];
-#pragma unroll
-            for (int r = 0; r < kFirR; ++r) acc[r] = (v2f){0.f, 0.f};
-            const v2f* xs = reinterpret_cast<const v2f*>(s_x) + wv * 64 + lane;
-            v2f ring[kFirDepth];
-            fir_prime(ring, xs, std::make_integer_sequence<int, kFirDepth>{});
-            __builtin_amdgcn_sched_barrier(0);
-            fir_steps(acc, ring, xs, tp, std::make_integer_sequence<int, kFirR + 110>{});
-            if (lane_on) {
-                float4* dst = reinterpret_cast<float4*>(iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + out0);
-#pragma unroll
-                for (int r = 0; r < kFirR; r += 2) dst[r / 2] = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
-            }
-            __syncthreads();
-        }
-        // ---- oscillator advance to the next field (offset.h:35-41)
-#pragma unroll
-        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
-    }
-
-    // The block that handled the last fields of channel group 0 publishes the advanced oscillator slice.
-    if (blockIdx.y == 0 && f_hi == fields && pos_main < kPaddedSyms) {
-        float4* p = reinterpret_cast<float4*>(osc_out + pos_main);
-#pragma unroll
-        for (int j = 0; j < kFirR / 2; ++j) p[j] = make_float4(tm[2 * j].x, tm[2 * j].y, tm[2 * j + 1].x, tm[2 * j + 1].y);
-    }
-}
-
-// --------------------------------------------------------------------------------------- fast-FIR variant
-// 2-parallel fast FIR (FFA): with xe[m]=x[2m], xo[m]=x[2m+1], xs=xe+xo and the half-rate tap sets
-// h0[k]=c[2k], h1[k]=c[2k+1], hs=h0+h1 (56 taps each; h1[55]=c[111]=0):
-//     P[n] = sum_k h1[k] xe[n+k]    Q[n] = sum_k h0[k] xo[n+k]    S[n] = sum_k hs[k] xs[n+k]
-//     y[2n] = S[n] - P[n] - Q[n]          y[2n+1] = Q[n] + P[n+1]
-// i.e. 3 half-length filters per output pair instead of 4: a lane's 8 outputs cost 5*55 + 4*56 + 4*56 = 723
-// packed FMAs instead of 888.  Same staging, same register-resident oscillator, same sliding windows (now
-// over the three half-rate streams, LDS transposed by (index mod 4)).  h0/h1 come from the same 28 SGPR tap
-// pairs as the direct form; the 56 unsymmetric hs taps are read as LDS broadcasts into a small VGPR ring.
-// fp32 error vs the reference stays at the direct form's level (6e-7 measured; tolerance 1e-5).
-__constant__ float c_taps_hs[56];
-
-hipError_t upload_taps_ffa(const float* taps112) {
-    float hs[56];
-    for (int k = 0; k < 56; ++k) hs[k] = taps112[2 * k] + taps112[2 * k + 1];
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_taps_hs), hs, sizeof hs);
-}
-
-constexpr int kFfaNp = kFirR / 2;          // output pairs per lane (4)
-constexpr int kFfaSteps = kFfaNp + 55;     // half-rate samples a lane slides over (59)
-constexpr int kFfaDepth = 4;               // sample reads in flight per stream
-constexpr int kFfaTapRing = 6;             // hs tap pairs held in VGPRs
-constexpr int kFfaTapAhead = 3;            // pair m is read 2*kFfaTapAhead steps before its first use
-
-__device__ __forceinline__ void fir_fma_v(v2f& acc, const v2f x, const v2f tap_pair, const int odd) {
-    if (odd)
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(x), "v"(tap_pair));
-    else
-        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(x), "v"(tap_pair));
-}
-
-__device__ __forceinline__ constexpr int ffa_off(int j) { return (j % 4) * kFirCols + j / 4; }
-
-template <int J>
-__device__ __forceinline__ void ffa_step_pq(v2f (&P)[kFfaNp + 1], v2f (&Q)[kFfaNp], v2f (&re)[kFfaDepth],
-                                            v2f (&ro)[kFfaDepth], const v2f* se, const v2f* so,
-                                            const unsigned long long (&tp)[28]) {
-    const v2f xe = re[J % kFfaDepth];
-    const v2f xo = ro[J % kFfaDepth];
-    if constexpr (J + kFfaDepth < kFfaSteps) {
-        re[J % kFfaDepth] = se[ffa_off(J + kFfaDepth)];
-        ro[J % kFfaDepth] = so[ffa_off(J + kFfaDepth)];
-    }
-#pragma unroll
-    for (int r = 0; r <= kFfaNp; ++r) {
-        const int k = J - r;
-        if (k >= 0 && k <= 54) fir_fma(P[r], xe, tp, 2 * k + 1);   // h1[k] = c[2k+1]
-    }
-#pragma unroll
-    for (int r = 0; r < kFfaNp; ++r) {
-        const int k = J - r;
-        if (k >= 0 && k <= 55) fir_fma(Q[r], xo, tp, 2 * k);       // h0[k] = c[2k]
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int... Js>
-__device__ __forceinline__ void ffa_steps_pq(v2f (&P)[kFfaNp + 1], v2f (&Q)[kFfaNp], v2f (&re)[kFfaDepth],
-                                             v2f (&ro)[kFfaDepth], const v2f* se, const v2f* so,
-                                             const unsigned long long (&tp)[28], std::integer_sequence<int, Js...>) {
-    (ffa_step_pq<Js>(P, Q, re, ro, se, so, tp), ...);
-}
-
-template <int J>
-__device__ __forceinline__ void ffa_step_s(v2f (&S)[kFfaNp], v2f (&rs)[kFfaDepth], v2f (&tr)[kFfaTapRing],
-                                           const v2f* ss, const v2f* taps) {
-    const v2f xs = rs[J % kFfaDepth];
-    if constexpr (J + kFfaDepth < kFfaSteps) rs[J % kFfaDepth] = ss[ffa_off(J + kFfaDepth)];
-    if constexpr ((J % 2) == 0 && J / 2 + kFfaTapAhead < 28) tr[(J / 2 + kFfaTapAhead) % kFfaTapRing] = taps[J / 2 + kFfaTapAhead];
-#pragma unroll
-    for (int r = 0; r < kFfaNp; ++r) {
-        const int k = J - r;
-        if (k >= 0 && k <= 55) fir_fma_v(S[r], xs, tr[(k >> 1) % kFfaTapRing], k & 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int... Js>
-__device__ __forceinline__ void ffa_steps_s(v2f (&S)[kFfaNp], v2f (&rs)[kFfaDepth], v2f (&tr)[kFfaTapRing],
-                                            const v2f* ss, const v2f* taps, std::integer_sequence<int, Js...>) {
-    (ffa_step_s<Js>(S, rs, tr, ss, taps), ...);
-}
-
-__global__ __launch_bounds__(kFirThreads) void k_mix_fir_ffa(const uint8_t* __restrict__ sym, size_t sym_stride,
-                                                             float2* __restrict__ iq, size_t iq_stride,
-                                                             const float2* __restrict__ osc_in,
-                                                             float2* __restrict__ osc_out, float2 scale, int channels,
-                                                             int fields, int ch_per_group, int f_per_group) {
-    __shared__ float2 s_e[4 * kFirCols];  // x[2m]            transposed by (m mod 4)
-    __shared__ float2 s_o[4 * kFirCols];  // x[2m+1]
-    __shared__ float2 s_s[4 * kFirCols];  // x[2m] + x[2m+1]
-    __shared__ float2 s_hs[28];           // hs tap pairs
-    const int tid = threadIdx.x;
-    const int tile = blockIdx.x;
-    const int c_lo = blockIdx.y * ch_per_group, c_hi = min(channels, c_lo + ch_per_group);
-    const int f_lo = blockIdx.z * f_per_group, f_hi = min(fields, f_lo + f_per_group);
-    const bool halo = tid < (kFirCols - kFirThreads);
-    const int pos_main = tile * kFirTile + kFirR * tid;
-    const int pos_halo = (tile + 1) * kFirTile + kFirR * tid;
-
-    unsigned long long tp[28];
-#pragma unroll
-    for (int m = 0; m < 28; ++m) tp[m] = c_tap_pairs[m];
-    if (tid < 28) s_hs[tid] = make_float2(c_taps_hs[2 * tid], c_taps_hs[2 * tid + 1]);
-
-    float2 tm[kFirR], th[kFirR];
-    load_osc8(osc_in, pos_main, true, tm);
-    load_osc8(osc_in, pos_halo, halo, th);
-    for (int n = 0; n < f_lo; ++n) {
-#pragma unroll
-        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
-    }
-
-    const int out0 = tile * kFirTile + kFirR * tid;  // first output of this lane (lane = pairs 4*tid .. 4*tid+3)
-    const bool lane_on = out0 < kFieldSyms;
-
-    SymRegs sm, sh;
-    {
-        const uint8_t* sf = sym + (size_t)c_lo * sym_stride + (size_t)f_lo * kFieldSyms;
-        sm = load_syms(sf, pos_main);
-        sh = halo ? load_syms(sf, pos_halo) : SymRegs{0u, 0u, false};
-    }
-
-    for (int f = f_lo; f < f_hi; ++f) {
-        for (int c = c_lo; c < c_hi; ++c) {
-            // ---- stage: mixed samples split into even / odd / sum half-rate streams
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const float x0 = sm.on ? level_of(p < 2 ? sm.lo : sm.hi, (2 * p) & 3) : 0.0f;
-                const float x1 = sm.on ? level_of(p < 2 ? sm.lo : sm.hi, (2 * p + 1) & 3) : 0.0f;
-                const float2 a = make_float2(__fmul_rn(x0, tm[2 * p].x), __fmul_rn(x0, tm[2 * p].y));
-                const float2 b = make_float2(__fmul_rn(x1, tm[2 * p + 1].x), __fmul_rn(x1, tm[2 * p + 1].y));
-                s_e[p * kFirCols + tid] = a;
-                s_o[p * kFirCols + tid] = b;
-                s_s[p * kFirCols + tid] = make_float2(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y));
-            }
-            if (halo) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float x0 = sh.on ? level_of(p < 2 ? sh.lo : sh.hi, (2 * p) & 3) : 0.0f;
-                    const float x1 = sh.on ? level_of(p < 2 ? sh.lo : sh.hi, (2 * p + 1) & 3) : 0.0f;
-                    const float2 a = make_float2(__fmul_rn(x0, th[2 * p].x), __fmul_rn(x0, th[2 * p].y));
-                    const float2 b = make_float2(__fmul_rn(x1, th[2 * p + 1].x), __fmul_rn(x1, th[2 * p + 1].y));
-                    s_e[p * kFirCols + kFirThreads + tid] = a;
-                    s_o[p * kFirCols + kFirThreads + tid] = b;
-                    s_s[p * kFirCols + kFirThreads + tid] = make_float2(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y));
-                }
-            }
-            __syncthreads();
-
-            // ---- prefetch the next (channel, field) symbols
-            {
-                int cn = c + 1, fn = f;
-                if (cn == c_hi) { cn = c_lo; fn = f + 1; }
-                if (fn < f_hi) {
-                    const uint8_t* sf = sym + (size_t)cn * sym_stride + (size_t)fn * kFieldSyms;
-                    sm = load_syms(sf, pos_main);
-                    if (halo) sh = load_syms(sf, pos_halo);
-                }
-            }
-
-            const v2f* se = reinterpret_cast<const v2f*>(s_e) + tid;
-            const v2f* so = reinterpret_cast<const v2f*>(s_o) + tid;
-            const v2f* ss = reinterpret_cast<const v2f*>(s_s) + tid;
-            const v2f* taps = reinterpret_cast<const v2f*>(s_hs);
-
-            v2f P[kFfaNp + 1], Q[kFfaNp], S[kFfaNp];
-#pragma unroll
-            for (int r = 0; r <= kFfaNp; ++r) P[r] = (v2f){0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < kFfaNp; ++r) { Q[r] = (v2f){0.f, 0.f}; S[r] = (v2f){0.f, 0.f}; }
-
-            {   // phase 1: P and Q share the walk over the even / odd streams
-                v2f re[kFfaDepth], ro[kFfaDepth];
-#pragma unroll
-                for (int j = 0; j < kFfaDepth; ++j) { re[j] = se[ffa_off(j)]; ro[j] = so[ffa_off(j)]; }
-                __builtin_amdgcn_sched_barrier(0);
-                ffa_steps_pq(P, Q, re, ro, se, so, tp, std::make_integer_sequence<int, kFfaSteps>{});
-            }
-            {   // phase 2: S over the sum stream, taps from LDS broadcasts
-                v2f rs[kFfaDepth], tr[kFfaTapRing];
-#pragma unroll
-                for (int j = 0; j < kFfaDepth; ++j) rs[j] = ss[ffa_off(j)];
-#pragma unroll
-                for (int m = 0; m < kFfaTapAhead; ++m) tr[m] = taps[m];
-                __builtin_amdgcn_sched_barrier(0);
-                ffa_steps_s(S, rs, tr, ss, taps, std::make_integer_sequence<int, kFfaSteps>{});
-            }
-#if ATSC_ABLATE == 1
-            {
-#pragma unroll
-                for (int r = 0; r < kFfaNp; ++r) {
-                    const v2f y0 = (S[r] - P[r]) - Q[r];
-                    const v2f y1 = Q[r] + P[r + 1];
-                    asm volatile("" ::"v"(y0), "v"(y1));
-                }
-            }
-#else
-            if (lane_on) {
-                float4* dst = reinterpret_cast<float4*>(iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + out0);
-#pragma unroll
-                for (int r = 0; r < kFfaNp; ++r) {
-                    const v2f y0 = (S[r] - P[r]) - Q[r];
-                    const v2f y1 = Q[r] + P[r + 1];
-                    dst[r] = make_float4(y0.x, y0.y, y1.x, y1.y);
-                }
-            }
-#endif
-            __syncthreads();
-        }
-#pragma unroll
-        for (int j = 0; j < kFirR; ++j) { tm[j] = osc_step(tm[j], scale); th[j] = osc_step(th[j], scale); }
-    }
-
-    if (blockIdx.y == 0 && f_hi == fields && pos_main < kPaddedSyms) {
-        float4* p = reinterpret_cast<float4*>(osc_out + pos_main);
-#pragma unroll
-        for (int j = 0; j < kFirR / 2; ++j) p[j] = make_float4(tm[2 * j].x, tm[2 * j].y, tm[2 * j + 1].x, tm[2 * j + 1].y);
-    }
-}
-
-void launch_mix_fir(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
-                    const float2* osc_in, float2* osc_out, float2 scale, int channels, int fields) {
-    // Decomposition: 128 tiles x channel groups x field groups, aiming at >= ~2048 blocks (8 per CU).
-    static const int target_blocks = [] { const char* e = getenv("ATSC_FIR_BLOCKS"); return e ? atoi(e) : 2048; }();
-    const int target = target_blocks / kFirTiles;  // (channel group, field group) pairs
-    int ngroups_c = channels < target ? channels : target;
-    int ch_per_group = (channels + ngroups_c - 1) / ngroups_c;
-    ngroups_c = (channels + ch_per_group - 1) / ch_per_group;
-    int ngroups_f = target / ngroups_c;
-    if (ngroups_f < 1) ngroups_f = 1;
-    if (ngroups_f > fields) ngroups_f = fields;
-    int f_per_group = (fields + ngroups_f - 1) / ngroups_f;
-    ngroups_f = (fields + f_per_group - 1) / f_per_group;
-    dim3 grid(kFirTiles, ngroups_c, ngroups_f);
-    static const int variant = [] { const char* e = getenv("ATSC_FIR_VARIANT"); return e ? atoi(e) : 1; }();
-    if (variant == 0)
-        hipLaunchKernelGGL(k_mix_fir, grid, dim3(kFirThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_in, osc_out,
-                           scale, channels, fields, ch_per_group, f_per_group);
-    else
-        hipLaunchKernelGGL(k_mix_fir_ffa, grid, dim3(kFirThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_in,
-                           osc_out, scale, channels, fields, ch_per_group, f_per_group);
 }
 
 // ======================================================================================= K6 oscillator advance

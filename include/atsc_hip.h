@@ -58,6 +58,7 @@ enum {
     ATSC_HIP_STAGE_TRELLIS_PAR,   /* per-part precoder/trellis parities                   */
     ATSC_HIP_STAGE_TRELLIS_SCAN,  /* exclusive XOR scan of the parities  -> carries       */
     ATSC_HIP_STAGE_TRELLIS_MAP,   /* trellis + 8-level map + sync insert -> u8 symbols    */
+    ATSC_HIP_STAGE_OSC,           /* oscillator table of the batch (or the bare state advance)   */
     ATSC_HIP_STAGE_MIX_FIR,       /* pilot/offset mixer + RRC FIR        -> complex64 IQ  */
     ATSC_HIP_STAGE_STATE,         /* end-of-batch state save                               */
     ATSC_HIP_NSTAGES
