@@ -77,7 +77,7 @@ extern "C" const char* atsc_hip_error_string(int code) {
 static int destroy_impl(atsc_hip_encoder* e) {
     if (!e) return 0;
     hipSetDevice(e->cfg.device);
-    hipFree(e->buf.coded); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
+    hipFree(e->buf.coded); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
     hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
     hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc_tab); hipFree(e->d_tables);
     hipFree(e->d_ts); hipFree(e->d_iq);
@@ -113,20 +113,22 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     } while (0)
 
     // constant tables: one allocation [prbs188 | rs_rows | fsync even | fsync odd]
-    const size_t off_prbs = 0, off_rows = align_up(kFieldTs, 256), off_fs = off_rows + 256 * 32;
+    const size_t off_prbs = 0, off_rows = align_up(kFieldTs, 256), off_pp = off_rows + atsc_tables::kRsLdsBytes, off_fs = off_pp + kPackets * 32;
     const size_t tab_bytes = off_fs + 2 * kSegSyms;
     TRY_OR_FREE(hipMalloc(&e->d_tables, tab_bytes));
     {
         std::vector<uint8_t> h(tab_bytes, 0);
         std::memcpy(h.data() + off_prbs, e->tab.prbs188.data(), kFieldTs);
-        std::memcpy(h.data() + off_rows, e->tab.rs_rows.data(), 256 * 32);
+        std::memcpy(h.data() + off_rows, e->tab.rs_lds.data(), atsc_tables::kRsLdsBytes);
+        std::memcpy(h.data() + off_pp, e->tab.prbs_parity.data(), kPackets * 32);
         std::memcpy(h.data() + off_fs, e->tab.fsync[0].data(), kSegSyms);
         std::memcpy(h.data() + off_fs + kSegSyms, e->tab.fsync[1].data(), kSegSyms);
         TRY_OR_FREE(hipMemcpy(e->d_tables, h.data(), tab_bytes, hipMemcpyHostToDevice));
     }
     auto* tb = static_cast<uint8_t*>(e->d_tables);
     e->dtab.prbs188 = reinterpret_cast<const uint32_t*>(tb + off_prbs);
-    e->dtab.rs_rows = reinterpret_cast<const uint4*>(tb + off_rows);
+    e->dtab.rs_lds = reinterpret_cast<const uint4*>(tb + off_rows);
+    e->dtab.prbs_parity = reinterpret_cast<const uint4*>(tb + off_pp);
     e->dtab.fsync = tb + off_fs;
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
 
@@ -136,6 +138,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     e->buf.il_stride = align_up(F * kFieldCoded, 256);
     e->sym_stride = F * kFieldSyms;
     TRY_OR_FREE(hipMalloc(&e->buf.coded, C * e->buf.coded_stride));
+    TRY_OR_FREE(hipMalloc(&e->buf.parity, C * F * kPackets * 32));
     TRY_OR_FREE(hipMalloc(&e->buf.il, C * e->buf.il_stride));
     TRY_OR_FREE(hipMalloc(&e->buf.par, C * F * kParts * sizeof(uint4)));
     TRY_OR_FREE(hipMalloc(&e->buf.cin, C * F * kParts * sizeof(uint4)));

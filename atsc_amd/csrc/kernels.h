@@ -29,13 +29,15 @@ constexpr int kOscTabSlack = 1024;  // complex64 entries behind the oscillator t
 
 struct DeviceTables {
     const uint32_t* prbs188;   // 58656 B, TS-field layout, dword view
-    const uint4* rs_rows;      // 256 rows x 32 B
+    const uint4* rs_lds;       // 98304 B: RS lookup tables in the LDS image of k_rs_parity (tables.h rs_lds)
+    const uint4* prbs_parity;  // 312 x 32 B: RS parity of every PRBS row
     const uint8_t* fsync;      // 2 x 832 B (even, odd)
 };
 
 struct Buffers {
     // [channel] strides in bytes
     uint8_t* coded;  size_t coded_stride;   // per channel: [kTail history | fields*64584]
+    uint4* parity;                           // [channel][fields*312] x 32 B: RS parity per packet (20 bytes used)
     uint8_t* il;     size_t il_stride;      // per channel: fields*64584, transmission order
     uint4* par;                              // [channel][fields*26] parities (3 words used)
     uint4* cin;                              // [channel][fields*26] carries entering each part

@@ -17,88 +17,154 @@
 namespace atsc_k {
 
 // ======================================================================================= K1 rand + RS
-// One thread owns one packet and runs the systematic LFSR byte-serially; the 20 GF(256) constant
-// multiplies of a step come from ONE 32-byte LDS row indexed by the feedback byte (row[fb] =
-// {g19*fb .. g0*fb}), so a step is 2 LDS reads + a 160-bit byte shift + 5 XORs.  Packets are staged
-// through LDS with coalesced dword loads (PRBS XOR fused into the load) and written back as whole
-// dwords of the 207-byte coded packets.  LDS rows are 53 dwords (odd) so the per-thread row walk is
-// bank-conflict-free.
-constexpr int kRsThreads = 256;
-constexpr int kRsRowDw = 53;
+// Two kernels.
+//
+// k_rs_parity: one lane = one TS packet, held whole in registers (47 dwords, read straight from HBM), and the
+// systematic LFSR run four data bytes per step: with u = (first four state bytes) ^ (next four data bytes) the new
+// state is shift4(state) ^ T4[u0] ^ T3[u1] ^ T2[u2] ^ T1[u3] (tables.cpp) -- per TS dword one XOR, four byte
+// extracts, 8 LDS reads (four 20-byte rows) and 20 XORs; the 4-byte shift of the 160-bit register is a renaming.
+// The dropped TS sync byte (randomize.h:48) is fed as a zero, which leaves a zero state untouched, so a packet is
+// exactly 47 steps.  The code is GF(2)-linear, so the raw TS bytes are encoded and the (precomputed) parity of the
+// packet's PRBS row is added at the end.  The row lookups are the cost: lanes read random rows, so the tables sit in
+// LDS in a bank-spread image (4 copies of the 16-byte part, 8 of the 4-byte part; lanes that share a copy collide only
+// within v mod 4), and nothing else lives in LDS so that 16 waves per CU hide the lookup latency.
+//
+// k_assemble: coded[207 s + k] = ts[188 s + 1 + k] ^ prbs[187 s + k] (k < 187) followed by the 20 parity bytes:
+// a byte-shifting copy, staged through LDS rows of 212 bytes (53 dwords, odd) with coalesced loads and stores.
+constexpr int kRsThreads = 1024;
 
-__global__ __launch_bounds__(kRsThreads) void k_rand_rs(const uint8_t* __restrict__ ts, size_t ts_stride,
-                                                        uint8_t* __restrict__ coded, size_t coded_stride,
-                                                        const uint32_t* __restrict__ prbs188,
-                                                        const uint4* __restrict__ rs_rows, int fields) {
-    __shared__ uint32_t s_pkt[kRsThreads * kRsRowDw];  // 54272 B
-    __shared__ uint4 s_rows[512];                      // 8192 B: 256 rows x 2 uint4
+typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ __launch_bounds__(kRsThreads) void k_rs_parity(const uint8_t* __restrict__ ts, const uint4* __restrict__ rs_lds,
+                                                          const uint4* __restrict__ prbs_parity,
+                                                          uint4* __restrict__ parity, long npackets) {
+    __shared__ uint4 s_a[4 * 256 * 4];      // 65536 B
+    __shared__ uint32_t s_e[4 * 256 * 8];   // 32768 B
     const int tid = threadIdx.x;
-    const int c = blockIdx.y;
-    const int pkt0 = blockIdx.x * kRsThreads;
-    const int total = fields * kPackets;
-    const int npk = min(kRsThreads, total - pkt0);
-
-    s_rows[tid] = rs_rows[tid];
-    s_rows[tid + 256] = rs_rows[tid + 256];
-
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride + (size_t)pkt0 * kTsBytes);
-    const int ndw = npk * 47;
-    for (int i = tid; i < ndw; i += kRsThreads) {
-        const int q = i / 47;
-        const int w = i - q * 47;
-        const int s = (pkt0 + q) % kPackets;
-        s_pkt[q * kRsRowDw + w] = src[i] ^ prbs188[s * 47 + w];
-    }
-    __syncthreads();
-
-    if (tid < npk) {
-        uint32_t* row = s_pkt + tid * kRsRowDw;
-        const uint32_t* rows32 = reinterpret_cast<const uint32_t*>(s_rows);
-        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
-#pragma unroll 1
-        for (int w = 0; w < 47; ++w) {
-            const uint32_t d = row[w];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (w == 0 && j == 0) continue;  // TS sync byte: dropped unchecked (randomize.h:48)
-                const uint32_t fb = ((d >> (8 * j)) ^ b0) & 0xffu;
-                const uint4 r = *reinterpret_cast<const uint4*>(rows32 + fb * 8);
-                const uint32_t r4 = rows32[fb * 8 + 4];
-                b0 = __builtin_amdgcn_alignbyte(b1, b0, 1) ^ r.x;
-                b1 = __builtin_amdgcn_alignbyte(b2, b1, 1) ^ r.y;
-                b2 = __builtin_amdgcn_alignbyte(b3, b2, 1) ^ r.z;
-                b3 = __builtin_amdgcn_alignbyte(b4, b3, 1) ^ r.w;
-                b4 = (b4 >> 8) ^ r4;
+    for (int i = 0; i < 4; ++i) s_a[tid + kRsThreads * i] = rs_lds[tid + kRsThreads * i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) reinterpret_cast<uint4*>(s_e)[tid + kRsThreads * i] = rs_lds[4096 + tid + kRsThreads * i];
+    __syncthreads();
+
+    const uint4* ta = s_a + (tid & 3);
+    const uint32_t* te = s_e + (tid & 7);
+    for (long P = (long)blockIdx.x * kRsThreads + tid; P < npackets; P += (long)gridDim.x * kRsThreads) {
+        uint32_t d[48];
+        {
+            const u32x4a4* src = reinterpret_cast<const u32x4a4*>(ts + P * kTsBytes);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) {
+                const u32x4a4 v = src[i];
+                d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
             }
+            const uint32_t* tail = reinterpret_cast<const uint32_t*>(ts + P * kTsBytes) + 44;
+            d[44] = tail[0]; d[45] = tail[1]; d[46] = tail[2];
         }
-        row[47] = b0; row[48] = b1; row[49] = b2; row[50] = b3; row[51] = b4;
+        d[0] &= 0xffffff00u;  // TS sync byte: dropped unchecked (randomize.h:48)
+        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+#pragma unroll
+        for (int w = 0; w < 47; ++w) {
+            const uint32_t u = d[w] ^ b0;
+            // first byte in time = lowest byte = four steps from the end -> table T4 (index 3)
+            const uint32_t i4 = 3 * 256 + (u & 0xffu), i3 = 2 * 256 + ((u >> 8) & 0xffu), i2 = 256 + ((u >> 16) & 0xffu),
+                           i1 = u >> 24;
+            const uint4 r4 = ta[i4 * 4], r3 = ta[i3 * 4], r2 = ta[i2 * 4], r1 = ta[i1 * 4];
+            const uint32_t e = te[i4 * 8] ^ te[i3 * 8] ^ te[i2 * 8] ^ te[i1 * 8];
+            b0 = b1 ^ r4.x ^ r3.x ^ r2.x ^ r1.x;
+            b1 = b2 ^ r4.y ^ r3.y ^ r2.y ^ r1.y;
+            b2 = b3 ^ r4.z ^ r3.z ^ r2.z ^ r1.z;
+            b3 = b4 ^ r4.w ^ r3.w ^ r2.w ^ r1.w;
+            b4 = e;
+        }
+        const int s = (int)(P % kPackets);
+        const uint4 pa = prbs_parity[2 * s];
+        const uint32_t pe = reinterpret_cast<const uint32_t*>(prbs_parity)[8 * s + 4];
+        parity[2 * P] = make_uint4(b0 ^ pa.x, b1 ^ pa.y, b2 ^ pa.z, b3 ^ pa.w);
+        reinterpret_cast<uint32_t*>(parity)[8 * P + 4] = b4 ^ pe;
+    }
+}
+
+constexpr int kAsmPackets = 64;   // packets per block: 64 * 207 bytes = 3312 dwords, a whole number of dwords
+constexpr int kAsmRowDw = 53;
+
+__global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ ts, size_t ts_stride,
+                                                  const uint32_t* __restrict__ parity, uint8_t* __restrict__ coded,
+                                                  size_t coded_stride, const uint32_t* __restrict__ prbs188, int fields) {
+    __shared__ uint32_t s_pkt[kAsmPackets * kAsmRowDw];  // 13568 B
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = blockIdx.y;
+    const int pkt0 = blockIdx.x * kAsmPackets;
+    const int total = fields * kPackets;             // a multiple of 8
+    const int npk = min(kAsmPackets, total - pkt0);  // a multiple of 8 as well
+
+    // The block's TS run as flat dwords (coalesced, all loads in flight at once) ^ PRBS, then the 5 parity dwords of
+    // every packet, into LDS rows of 53 dwords.  The PRBS repeats every field = 312 * 47 dwords.
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride + (size_t)pkt0 * kTsBytes);
+    const uint32_t* par = parity + ((size_t)c * total + pkt0) * 8;
+    const int ndw = npk * 47;
+    uint32_t v[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int i = tid + 256 * k;
+        const int n = (pkt0 * 47 + i) % (kPackets * 47);
+        v[k] = i < ndw ? src[i] ^ prbs188[n] : 0u;
+    }
+    uint32_t pv[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k;
+        pv[k] = i < npk * 5 ? par[(i / 5) * 8 + i % 5] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const int i = tid + 256 * k;
+        if (i < ndw) s_pkt[i + 6 * (i / 47)] = v[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k;
+        if (i < npk * 5) s_pkt[(i / 5) * kAsmRowDw + 47 + i % 5] = pv[k];
     }
     __syncthreads();
 
-    // Coded packet q = row bytes 1..207 (187 randomized data bytes, then bb[0..19]).
+    // Coded packet q = row bytes 1..207.  Four packets = 828 bytes = 207 whole dwords: lane j of a group assembles
+    // dword j from bytes 4j..4j+3 of the group, which sit in packet (4j+i)/207 at row byte 1 + (4j+i)%207.
     const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_pkt);
     uint32_t* dst = reinterpret_cast<uint32_t*>(coded + (size_t)c * coded_stride + kTail + (size_t)pkt0 * kSegCoded);
-    const int nout = npk * kSegCoded / 4;  // npk*207 is a multiple of 4 for every block (see launch)
-    for (int i = tid; i < nout; i += kRsThreads) {
-        const int o = 4 * i;
-        const int q0 = o / kSegCoded;
-        const int r0 = o - q0 * kSegCoded;
-        uint32_t v = 0;
+    int off[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = q0 + ((r0 + j) >= kSegCoded ? 1 : 0);
-            v |= (uint32_t)s8[o + j + 1 + 5 * q] << (8 * j);  // 212*q + 1 + r with r = o+j-207q
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int beta = 4 * (lane + 64 * it) + i;
+            const int p = beta / kSegCoded;
+            off[it][i] = p * (kAsmRowDw * 4) + 1 + (beta - p * kSegCoded);
         }
-        dst[i] = v;
+    for (int grp = wv; grp < npk / 4; grp += 4) {
+        const uint8_t* g8 = s8 + grp * (4 * kAsmRowDw * 4);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int j = lane + 64 * it;
+            if (j < kSegCoded) {
+                const uint32_t v = (uint32_t)g8[off[it][0]] | ((uint32_t)g8[off[it][1]] << 8) |
+                                   ((uint32_t)g8[off[it][2]] << 16) | ((uint32_t)g8[off[it][3]] << 24);
+                dst[grp * kSegCoded + j] = v;
+            }
+        }
     }
 }
 
 void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                     int channels, int fields) {
+    // ts is [channels][fields][312][188] with ts_stride = fields * 58656: one flat run of packets
+    const long npackets = (long)channels * fields * kPackets;
+    const long want = (npackets + kRsThreads - 1) / kRsThreads;
+    const unsigned grid = (unsigned)(want < 1024 ? want : 1024);  // grid-stride: the 96 KB table image loads once per block
+    hipLaunchKernelGGL(k_rs_parity, dim3(grid), dim3(kRsThreads), 0, s, d_ts, t.rs_lds, t.prbs_parity, b.parity, npackets);
     const int total = fields * kPackets;
-    dim3 grid((total + kRsThreads - 1) / kRsThreads, channels);
-    hipLaunchKernelGGL(k_rand_rs, grid, dim3(kRsThreads), 0, s, d_ts, ts_stride, b.coded, b.coded_stride, t.prbs188,
-                       t.rs_rows, fields);
+    hipLaunchKernelGGL(k_assemble, dim3((total + kAsmPackets - 1) / kAsmPackets, channels), dim3(256), 0, s, d_ts, ts_stride,
+                       reinterpret_cast<const uint32_t*>(b.parity), b.coded, b.coded_stride, t.prbs188, fields);
 }
 
 // ======================================================================================= K2 interleaver

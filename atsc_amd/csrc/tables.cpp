@@ -58,6 +58,41 @@ void build_rs(Tables& t) {
     t.rs_rows.assign(256 * 32, 0);
     for (int fb = 0; fb < 256; ++fb)
         for (int i = 0; i < kParity; ++i) t.rs_rows[fb * 32 + i] = gf.mul(g[kParity - 1 - i], static_cast<uint8_t>(fb));
+    // Four data bytes per step.  One LFSR step is s' = L(s ^ x e0) with the linear map L(v) = shift(v) ^ row[v[0]], so
+    // after four steps   s4 = shift4(s) ^ T4[s0^d0] ^ T3[s1^d1] ^ T2[s2^d2] ^ T1[s3^d3],   Tm[v] = L^m(v e0), T1 = row.
+    // Stored [m-1][v] as 32-byte rows.
+    t.rs_rows4.assign(4 * 256 * 32, 0);
+    for (int v = 0; v < 256; ++v) {
+        uint8_t st[kParity] = {static_cast<uint8_t>(v)};
+        for (int m = 1; m <= 4; ++m) {
+            const uint8_t* row = &t.rs_rows[st[0] * 32];
+            uint8_t nx[kParity];
+            for (int i = 0; i < kParity; ++i) nx[i] = static_cast<uint8_t>((i + 1 < kParity ? st[i + 1] : 0) ^ row[i]);
+            std::memcpy(st, nx, sizeof st);
+            std::memcpy(&t.rs_rows4[((m - 1) * 256 + v) * 32], st, kParity);
+        }
+    }
+    // The same four tables in the bank-spread LDS image of k_rs_parity: the first 16 bytes of row (m, v) four times
+    // (copy = lane & 3) at 16-byte index (m*256 + v)*4 + copy, then the last 4 bytes eight times (copy = lane & 7) at
+    // dword index (m*256 + v)*8 + copy.  Lanes that share a copy spread over (v mod 4) only.
+    t.rs_lds.assign(kRsLdsBytes, 0);
+    for (int m = 0; m < 4; ++m)
+        for (int v = 0; v < 256; ++v) {
+            const uint8_t* row = &t.rs_rows4[(m * 256 + v) * 32];
+            for (int c = 0; c < 4; ++c) std::memcpy(&t.rs_lds[((m * 256 + v) * 4 + c) * 16], row, 16);
+            for (int c = 0; c < 8; ++c) std::memcpy(&t.rs_lds[65536 + ((m * 256 + v) * 8 + c) * 4], row + 16, 4);
+        }
+    // RS is linear, so the kernel encodes the raw TS bytes and adds the parity of the PRBS row afterwards.
+    t.prbs_parity.assign(kPackets * 32, 0);
+    for (int s = 0; s < kPackets; ++s) {
+        uint8_t st[kParity] = {0};
+        for (int k = 0; k < kSegData; ++k) {
+            const uint8_t fb = static_cast<uint8_t>(t.prbs[s * kSegData + k] ^ st[0]);
+            const uint8_t* row = &t.rs_rows[fb * 32];
+            for (int i = 0; i < kParity; ++i) st[i] = static_cast<uint8_t>((i + 1 < kParity ? st[i + 1] : 0) ^ row[i]);
+        }
+        std::memcpy(&t.prbs_parity[s * 32], st, kParity);
+    }
 }
 
 // ---- PN511 / PN63 and the field sync segment (reference: src/common/lfsr.h:10-26,
