@@ -77,7 +77,7 @@ extern "C" const char* atsc_hip_error_string(int code) {
 static int destroy_impl(atsc_hip_encoder* e) {
     if (!e) return 0;
     hipSetDevice(e->cfg.device);
-    hipFree(e->buf.coded); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
+    hipFree(e->buf.coded); hipFree(e->buf.tail); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
     hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
     hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc_tab); hipFree(e->d_tables);
     hipFree(e->d_ts); hipFree(e->d_iq);
@@ -113,8 +113,9 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     } while (0)
 
     // constant tables: one allocation [prbs188 | rs_rows | fsync even | fsync odd]
-    const size_t off_prbs = 0, off_rows = align_up(kFieldTs, 256), off_pp = off_rows + atsc_tables::kRsLdsBytes, off_fs = off_pp + kPackets * 32;
-    const size_t tab_bytes = off_fs + 2 * kSegSyms;
+    const size_t off_prbs = 0, off_rows = align_up(kFieldTs, 256), off_pp = off_rows + atsc_tables::kRsLdsBytes, off_fs = off_pp + kPackets * 32,
+                 off_pr = align_up(off_fs + 2 * kSegSyms, 256);
+    const size_t tab_bytes = off_pr + e->tab.prbs.size();
     TRY_OR_FREE(hipMalloc(&e->d_tables, tab_bytes));
     {
         std::vector<uint8_t> h(tab_bytes, 0);
@@ -123,6 +124,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
         std::memcpy(h.data() + off_pp, e->tab.prbs_parity.data(), kPackets * 32);
         std::memcpy(h.data() + off_fs, e->tab.fsync[0].data(), kSegSyms);
         std::memcpy(h.data() + off_fs + kSegSyms, e->tab.fsync[1].data(), kSegSyms);
+        std::memcpy(h.data() + off_pr, e->tab.prbs.data(), e->tab.prbs.size());
         TRY_OR_FREE(hipMemcpy(e->d_tables, h.data(), tab_bytes, hipMemcpyHostToDevice));
     }
     auto* tb = static_cast<uint8_t*>(e->d_tables);
@@ -130,6 +132,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     e->dtab.rs_lds = reinterpret_cast<const uint4*>(tb + off_rows);
     e->dtab.prbs_parity = reinterpret_cast<const uint4*>(tb + off_pp);
     e->dtab.fsync = tb + off_fs;
+    e->dtab.prbs = tb + off_pr;
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
 
     // per-channel working buffers
@@ -137,7 +140,8 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     e->buf.coded_stride = align_up(kTail + F * kFieldCoded, 256);
     e->buf.il_stride = align_up(F * kFieldCoded, 256);
     e->sym_stride = F * kFieldSyms;
-    TRY_OR_FREE(hipMalloc(&e->buf.coded, C * e->buf.coded_stride));
+    if (cfg->flags & ATSC_HIP_FLAG_TAPS) TRY_OR_FREE(hipMalloc(&e->buf.coded, C * e->buf.coded_stride));
+    TRY_OR_FREE(hipMalloc(&e->buf.tail, C * kTail));
     TRY_OR_FREE(hipMalloc(&e->buf.parity, C * F * kPackets * 32));
     TRY_OR_FREE(hipMalloc(&e->buf.il, C * e->buf.il_stride));
     TRY_OR_FREE(hipMalloc(&e->buf.par, C * F * kParts * sizeof(uint4)));
@@ -147,7 +151,8 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     TRY_OR_FREE(hipMalloc(&e->buf.last_group, C * 16));
     TRY_OR_FREE(hipMalloc(&e->d_sym, C * e->sym_stride));
     // zero history (reference: atsc.cpp:24-26,34; trellis.h:55-59)
-    TRY_OR_FREE(hipMemset(e->buf.coded, 0, C * e->buf.coded_stride));
+    if (e->buf.coded) TRY_OR_FREE(hipMemset(e->buf.coded, 0, C * e->buf.coded_stride));
+    TRY_OR_FREE(hipMemset(e->buf.tail, 0, C * kTail));
     TRY_OR_FREE(hipMemset(e->buf.carry, 0, C * sizeof(uint4)));
     TRY_OR_FREE(hipMemset(e->buf.span_par, 0, C * sizeof(uint4)));
     TRY_OR_FREE(hipMemset(e->buf.last_group, 0, C * 16));
@@ -207,12 +212,12 @@ int read_timings(atsc_hip_encoder* e, const atsc_hip_encoder::EventSet& set, flo
 // trellis state entering the batch
 int run_front(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, hipStream_t s) {
     const int C = e->cfg.channels;
+    const size_t ts_stride = (size_t)fields * kFieldTs;
     mark(e, s, ATSC_HIP_STAGE_RAND_RS);
-    launch_rand_rs(s, e->dtab, d_ts, (size_t)fields * kFieldTs, e->buf, C, fields);
+    launch_rand_rs(s, e->dtab, d_ts, ts_stride, e->buf, C, fields);
+    if (e->buf.coded) launch_assemble(s, e->dtab, d_ts, ts_stride, e->buf, C, fields);
     mark(e, s, ATSC_HIP_STAGE_INTERLEAVE);
-    launch_interleave(s, e->buf, C, fields);
-    mark(e, s, ATSC_HIP_STAGE_TRELLIS_PAR);
-    launch_trellis_parity(s, e->buf, C, fields);
+    launch_interleave(s, e->dtab, d_ts, ts_stride, e->buf, C, fields);  // + the per-part trellis parities
     return static_cast<int>(hipGetLastError());
 }
 
@@ -379,7 +384,7 @@ extern "C" int atsc_hip_export_state(atsc_hip_encoder* e, int channel, atsc_hip_
     HIP_TRY(hipDeviceSynchronize());
     std::memset(out, 0, sizeof *out);
     out->field_index = e->field_index;
-    HIP_TRY(hipMemcpy(out->coded_tail, e->buf.coded + (size_t)channel * e->buf.coded_stride, kTail, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out->coded_tail, e->buf.tail + (size_t)channel * kTail, kTail, hipMemcpyDeviceToHost));
     uint8_t lg[16];
     HIP_TRY(hipMemcpy(lg, e->buf.last_group + (size_t)channel * 16, 16, hipMemcpyDeviceToHost));
     std::memcpy(out->last_group, lg, 12);
@@ -398,7 +403,7 @@ extern "C" int atsc_hip_import_state(atsc_hip_encoder* e, int channel, const ats
     if (!e || !in || channel < 0 || channel >= e->cfg.channels) return ATSC_HIP_ERR_ARG;
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(e->buf.coded + (size_t)channel * e->buf.coded_stride, in->coded_tail, kTail, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(e->buf.tail + (size_t)channel * kTail, in->coded_tail, kTail, hipMemcpyHostToDevice));
     uint8_t lg[16] = {0};
     std::memcpy(lg, in->last_group, 12);
     HIP_TRY(hipMemcpy(e->buf.last_group + (size_t)channel * 16, lg, 16, hipMemcpyHostToDevice));
@@ -446,7 +451,9 @@ extern "C" int atsc_hip_stage_buffer(atsc_hip_encoder* e, int stage, void** d_pt
     size_t b = 0, st = 0;
     void* p = nullptr;
     switch (stage) {
-        case ATSC_HIP_STAGE_RAND_RS: p = e->buf.coded; st = e->buf.coded_stride; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_RAND_RS:
+            if (!e->buf.coded) return ATSC_HIP_ERR_STATE;  // handle created without ATSC_HIP_FLAG_TAPS
+            p = e->buf.coded; st = e->buf.coded_stride; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_INTERLEAVE: p = e->buf.il; st = e->buf.il_stride; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_TRELLIS_PAR: p = e->buf.par; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_TRELLIS_SCAN: p = e->buf.cin; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;

@@ -32,11 +32,13 @@ struct DeviceTables {
     const uint4* rs_lds;       // 98304 B: RS lookup tables in the LDS image of k_rs_parity (tables.h rs_lds)
     const uint4* prbs_parity;  // 312 x 32 B: RS parity of every PRBS row
     const uint8_t* fsync;      // 2 x 832 B (even, odd)
+    const uint8_t* prbs;       // 58344 B, plain order (187 per packet)
 };
 
 struct Buffers {
     // [channel] strides in bytes
-    uint8_t* coded;  size_t coded_stride;   // per channel: [kTail history | fields*64584]
+    uint8_t* coded;  size_t coded_stride;   // debug tap only (ATSC_HIP_FLAG_TAPS): per channel [kTail unused | fields*64584]
+    uint8_t* tail;                           // [channel][kTail]: last 10608 RS-coded bytes of the previous batch
     uint4* parity;                           // [channel][fields*312] x 32 B: RS parity per packet (20 bytes used)
     uint8_t* il;     size_t il_stride;      // per channel: fields*64584, transmission order
     uint4* par;                              // [channel][fields*26] parities (3 words used)
@@ -49,8 +51,12 @@ struct Buffers {
 
 void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                     int channels, int fields);
-void launch_interleave(hipStream_t s, const Buffers& b, int channels, int fields);
-void launch_trellis_parity(hipStream_t s, const Buffers& b, int channels, int fields);
+// interleaver + per-part trellis parities straight from TS + parity (+ the saved coded tail); then refreshes the tail
+void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
+                       int channels, int fields);
+// debug tap: materialises the RS-coded stream b.coded (not needed by the path itself)
+void launch_assemble(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
+                     int channels, int fields);
 void launch_trellis_scan(hipStream_t s, const Buffers& b, const uint4* carry_xor, int channels, int fields);
 void launch_span_parity(hipStream_t s, const Buffers& b, uint4* d_out, int channels, int fields);
 void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride,

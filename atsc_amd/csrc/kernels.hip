@@ -2,7 +2,7 @@
 //
 //   k_rand_rs        randomizer (PRBS XOR) + RS(207,187) parity            reference: randomize.h:43-54, reed_solomon.h:192-242
 //   k_interleave     52-branch convolutional byte interleaver as an LDS shear   reference: interleaver.h:11-108
-//   k_trellis_parity per-part GF(2) parities of the 12 precoders/trellis encoders  reference: trellis.h:10-51,240-242
+//                    (+ the per-part GF(2) parities of the 12 precoders/trellis encoders: trellis.h:10-51,240-242)
 //   k_trellis_scan   exclusive XOR scan of the parities -> carry entering every part
 //   k_trellis_map    precoder + trellis + 8-level map + segment/field sync -> u8 symbols   reference: trellis.h:121-499,549-576, field_sync.h:12-26
 //   (k_mix_fir_fft   pilot/offset mixer + 112-tap RRC FIR -> complex64: fir_fft.hip)
@@ -29,8 +29,9 @@ namespace atsc_k {
 // LDS in a bank-spread image (4 copies of the 16-byte part, 8 of the 4-byte part; lanes that share a copy collide only
 // within v mod 4), and nothing else lives in LDS so that 16 waves per CU hide the lookup latency.
 //
-// k_assemble: coded[207 s + k] = ts[188 s + 1 + k] ^ prbs[187 s + k] (k < 187) followed by the 20 parity bytes:
-// a byte-shifting copy, staged through LDS rows of 212 bytes (53 dwords, odd) with coalesced loads and stores.
+// k_assemble (debug tap, ATSC_HIP_FLAG_TAPS): coded[207 s + k] = ts[188 s + 1 + k] ^ prbs[187 s + k] (k < 187) followed
+// by the 20 parity bytes: a byte-shifting copy, staged through LDS rows of 212 bytes with coalesced loads and stores.
+// The path itself never materialises the coded stream: k_interleave reads TS + parity directly.
 constexpr int kRsThreads = 1024;
 
 typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -158,48 +159,18 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ ts
 void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                     int channels, int fields) {
     // ts is [channels][fields][312][188] with ts_stride = fields * 58656: one flat run of packets
+    (void)ts_stride;
     const long npackets = (long)channels * fields * kPackets;
     const long want = (npackets + kRsThreads - 1) / kRsThreads;
     const unsigned grid = (unsigned)(want < 1024 ? want : 1024);  // grid-stride: the 96 KB table image loads once per block
     hipLaunchKernelGGL(k_rs_parity, dim3(grid), dim3(kRsThreads), 0, s, d_ts, t.rs_lds, t.prbs_parity, b.parity, npackets);
+}
+
+void launch_assemble(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
+                     int channels, int fields) {
     const int total = fields * kPackets;
     hipLaunchKernelGGL(k_assemble, dim3((total + kAsmPackets - 1) / kAsmPackets, channels), dim3(256), 0, s, d_ts, ts_stride,
                        reinterpret_cast<const uint32_t*>(b.parity), b.coded, b.coded_stride, t.prbs188, fields);
-}
-
-// ======================================================================================= K2 interleaver
-// The coded stream of a channel viewed as rows of 52 bytes is sheared: IL[a][r] = E[a - 4r][r]
-// (IL[M] = E[M - 208*(M mod 52)], B=52, M=4).  A block produces 621 output rows (half
-// a field) from 825 source rows staged in LDS with coalesced dword loads; each output dword gathers 4
-// bytes that sit 207 bytes apart in LDS (odd dword stride -> conflict-free) and is stored coalesced.
-constexpr int kIlRows = 621;
-constexpr int kIlSrcDw = (kIlRows + 204) * 52 / 4;  // 10725
-constexpr int kIlOutDw = kIlRows * 52 / 4;          // 8073
-
-__global__ __launch_bounds__(256) void k_interleave(const uint8_t* __restrict__ coded, size_t coded_stride,
-                                                    uint8_t* __restrict__ il, size_t il_stride) {
-    __shared__ uint32_t s_src[kIlSrcDw];  // 42900 B
-    const int tid = threadIdx.x;
-    const int c = blockIdx.y;
-    const int h = blockIdx.x;  // half-field index within the batch
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(coded + (size_t)c * coded_stride + (size_t)h * (kIlRows * 52));
-    for (int i = tid; i < kIlSrcDw; i += 256) s_src[i] = src[i];
-    __syncthreads();
-    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_src);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(il + (size_t)c * il_stride + (size_t)h * (kIlRows * 52));
-    for (int d = tid; d < kIlOutDw; d += 256) {
-        const int a = d / 13;
-        const int r = 4 * (d - 13 * a);
-        const int base = (a + 204 - 4 * r) * 52 + r;
-        const uint32_t v = (uint32_t)s8[base] | ((uint32_t)s8[base - 207] << 8) | ((uint32_t)s8[base - 414] << 16) |
-                           ((uint32_t)s8[base - 621] << 24);
-        dst[d] = v;
-    }
-}
-
-void launch_interleave(hipStream_t s, const Buffers& b, int channels, int fields) {
-    dim3 grid(2 * fields, channels);
-    hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, b.coded, b.coded_stride, b.il, b.il_stride);
 }
 
 // ======================================================================================= trellis helpers
@@ -250,44 +221,146 @@ __device__ __forceinline__ uint32_t wave_xor_inclusive(uint32_t v, int lane) {
     return v;
 }
 
-// ======================================================================================= K3a parities
-__global__ __launch_bounds__(256) void k_trellis_parity(const uint8_t* __restrict__ il, size_t il_stride,
-                                                        uint4* __restrict__ par, int fields) {
-    __shared__ uint32_t s_red[4][3];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int c = blockIdx.z, f = blockIdx.y, p = blockIdx.x;
-    uint32_t pr[3] = {0, 0, 0};
-    if (tid < kPartGroups) {
-        const int g = p * kPartGroups + tid;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(il + (size_t)c * il_stride + (size_t)f * kFieldCoded) + 3 * g;
-        const Words3 e = canonical_group(src, g);
+// ======================================================================================= K2 interleaver
+// The coded stream of a channel viewed as rows of 52 bytes is sheared: IL[a][r] = E[a - 4r][r]
+// (IL[M] = E[M - 208*(M mod 52)], B=52, M=4).  A block produces 621 output rows (half a field) from
+// the 42900 coded bytes that start 10608 bytes earlier -- and those are never read from HBM as a coded stream: the
+// block stages the ~208 TS packets that hold them (flat coalesced dword loads, PRBS XOR fused: randomize.h:43-54)
+// plus their 20 parity bytes from k_rs_parity as LDS rows [sync | 187 data | 20 parity] of 53 dwords, i.e. coded
+// byte r of packet q sits at row byte 1 + r.  The four bytes of an output dword lie exactly 207 coded bytes = one
+// packet apart, so one (packet, offset) pair per dword addresses all four.  Packets before the batch (first block of
+// a batch only) come from the channel's saved 10608-byte coded tail.
+// Every thread assembles whole 12-byte groups, so the precoder/trellis parities of the 13 parts of the half-field
+// (reference: trellis.h:240-242) are folded in here (LDS XOR) and no separate pass re-reads the interleaved bytes.
+constexpr int kIlRows = 621;
+constexpr int kIlBytes = kIlRows * 52;               // 32292 output bytes = 2691 groups = 13 parts
+constexpr int kIlSrcBytes = (kIlRows + 204) * 52;    // 42900 coded bytes feed them
+constexpr int kIlGroups = kIlBytes / 12;             // 2691
+constexpr int kIlMaxPk = 210;                        // packets that can overlap 42900 coded bytes
+constexpr int kIlRowDw = 53;
+
+typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
+
+__global__ __launch_bounds__(256) void k_interleave(const uint8_t* __restrict__ ts, size_t ts_stride,
+                                                    const uint32_t* __restrict__ parity, const uint8_t* __restrict__ tail,
+                                                    const uint32_t* __restrict__ prbs188, uint8_t* __restrict__ il,
+                                                    size_t il_stride, uint4* __restrict__ par, int fields) {
+    __shared__ uint32_t s_pkt[kIlMaxPk * kIlRowDw];  // 44520 B
+    __shared__ uint32_t s_par[13 * 3][32];             // one XOR accumulator per (part, word, lane mod 32): no same-address traffic
+    const int tid = threadIdx.x;
+    const int c = blockIdx.y;
+    const int h = blockIdx.x;                          // half-field index within the batch
+    const int total = fields * kPackets;
+    const int o0 = h * kIlBytes - kTail;               // coded offset (batch-relative) of the first byte needed
+    const int q0 = (o0 + 52 * kSegCoded) / kSegCoded - 52;  // floor(o0 / 207), o0 >= -10608 > -52*207
+    const int q1 = (o0 + kIlSrcBytes - 1) / kSegCoded;      // last packet needed (>= 0, < total)
+    const int qa = q0 < 0 ? 0 : q0;                    // first packet that lies in this batch
+
+    for (int i = tid; i < 13 * 3 * 32; i += 256) (&s_par[0][0])[i] = 0;
+
+    // packets qa..q1 of this batch: TS dwords ^ PRBS (the PRBS repeats every field = 312*47 dwords), then parity
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride) + (size_t)qa * 47;
+        const int ndw = (q1 - qa + 1) * 47;
+        const int row0 = qa - q0;
+        for (int i0 = 0; i0 < ndw; i0 += 256 * 8) {
+            uint32_t v[8];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            uint32_t z2, z0;
-            trellis_local(e.w[k], z2, z0, pr[k]);
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + tid + 256 * k;
+                v[k] = i < ndw ? src[i] ^ prbs188[(qa * 47 + i) % (kPackets * 47)] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = i0 + tid + 256 * k;
+                if (i < ndw) s_pkt[row0 * kIlRowDw + i + 6 * (i / 47)] = v[k];
+            }
+        }
+        const uint32_t* pp = parity + ((size_t)c * total + qa) * 8;
+        const int npar = (q1 - qa + 1) * 5;
+        for (int i = tid; i < npar; i += 256) s_pkt[(row0 + i / 5) * kIlRowDw + 47 + i % 5] = pp[(i / 5) * 8 + i % 5];
+    }
+    // packets before the batch: coded byte o (-10608 <= o < 0) = tail[10608 + o]
+    if (q0 < 0) {
+        const uint8_t* tl = tail + (size_t)c * kTail;
+        uint8_t* s8w = reinterpret_cast<uint8_t*>(s_pkt);
+        for (int i = tid; i < kTail; i += 256) {
+            const int q = (i + (52 * kSegCoded - kTail)) / kSegCoded - 52;  // floor((i - 10608) / 207)
+            const int r = i - kTail - q * kSegCoded;
+            s8w[(q - q0) * (kIlRowDw * 4) + 1 + r] = tl[i];
         }
     }
+    __syncthreads();
+
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_pkt);
+    uint8_t* dst = il + (size_t)c * il_stride + (size_t)h * kIlBytes;
+    const int g_field0 = (h & 1) * kIlGroups;          // group index of this block's first group within its field
+    for (int g = tid; g < kIlGroups; g += 256) {
+        uint32_t dw[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        uint32_t v = pr[k];
+        for (int w = 0; w < 3; ++w) {
+            const int d = 3 * g + w;
+            const int a = d / 13;
+            const int r = 4 * (d - 13 * a);
+            const int abs0 = o0 + (a + 204 - 4 * r) * 52 + r;        // coded offset of byte 0; byte j sits 207*j earlier
+            const int q = (abs0 + 52 * kSegCoded) / kSegCoded - 52;   // floor
+            const int addr = (q - q0) * (kIlRowDw * 4) + 1 + (abs0 - q * kSegCoded);
+            dw[w] = (uint32_t)s8[addr] | ((uint32_t)s8[addr - kIlRowDw * 4] << 8) |
+                    ((uint32_t)s8[addr - 2 * kIlRowDw * 4] << 16) | ((uint32_t)s8[addr - 3 * kIlRowDw * 4] << 24);
+        }
+        u32x3a4 o3;
+        o3.x = dw[0]; o3.y = dw[1]; o3.z = dw[2];
+        *reinterpret_cast<u32x3a4*>(dst + 12 * g) = o3;
+        // parities of this byte-time for the 12 encoders
+        const Words3 e = canonical_group(dw, g_field0 + g);
+        const int p = g / kPartGroups;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v ^= __shfl_xor(v, d, 64);
-        if (lane == 0) s_red[wv][k] = v;
+        for (int k = 0; k < 3; ++k) {
+            uint32_t z2, z0, pr;
+            trellis_local(e.w[k], z2, z0, pr);
+            atomicXor(&s_par[3 * p + k][tid & 31], pr);
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        uint4 o;
-        o.x = s_red[0][0] ^ s_red[1][0] ^ s_red[2][0] ^ s_red[3][0];
-        o.y = s_red[0][1] ^ s_red[1][1] ^ s_red[2][1] ^ s_red[3][1];
-        o.z = s_red[0][2] ^ s_red[1][2] ^ s_red[2][2] ^ s_red[3][2];
-        o.w = 0;
-        par[((size_t)c * fields + f) * kParts + p] = o;
+    if (tid < 13 * 3) {  // fold the 32 slots (rotated start: conflict-free), then one uint4 per part
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) v ^= s_par[tid][(i + tid) & 31];
+        s_par[tid][0] = v;
+    }
+    __syncthreads();
+    if (tid < 13) {
+        const int f = h >> 1;
+        par[((size_t)c * fields + f) * kParts + (h & 1) * 13 + tid] =
+            make_uint4(s_par[3 * tid][0], s_par[3 * tid + 1][0], s_par[3 * tid + 2][0], 0);
     }
 }
 
-void launch_trellis_parity(hipStream_t s, const Buffers& b, int channels, int fields) {
-    dim3 grid(kParts, fields, channels);
-    hipLaunchKernelGGL(k_trellis_parity, grid, dim3(256), 0, s, b.il, b.il_stride, b.par, fields);
+// Coded tail of the batch (the last 10608 RS-coded bytes) for the next batch's first block and for state export.
+__global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ ts, size_t ts_stride,
+                                                   const uint8_t* __restrict__ parity, const uint8_t* __restrict__ prbs,
+                                                   uint8_t* __restrict__ tail, int fields) {
+    const int c = blockIdx.x;
+    const int total = fields * kPackets;
+    const uint8_t* tsc = ts + (size_t)c * ts_stride;
+    const uint8_t* pc = parity + (size_t)c * total * 32;
+    for (int i = threadIdx.x; i < kTail; i += 256) {
+        const int o = total * kSegCoded - kTail + i;   // >= 0: a batch is at least one field
+        const int q = o / kSegCoded, r = o - q * kSegCoded;
+        const uint8_t v = r < 187 ? (uint8_t)(tsc[(size_t)q * kTsBytes + 1 + r] ^ prbs[(q % kPackets) * 187 + r])
+                                  : pc[(size_t)q * 32 + (r - 187)];
+        tail[(size_t)c * kTail + i] = v;
+    }
+}
+
+void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
+                       int channels, int fields) {
+    dim3 grid(2 * fields, channels);
+    hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, d_ts, ts_stride, reinterpret_cast<const uint32_t*>(b.parity),
+                       b.tail, t.prbs188, b.il, b.il_stride, b.par, fields);
+    // the tail is consumed above and replaced by this batch's own (stream order)
+    hipLaunchKernelGGL(k_save_tail, dim3(channels), dim3(256), 0, s, d_ts, ts_stride,
+                       reinterpret_cast<const uint8_t*>(b.parity), t.prbs, b.tail, fields);
 }
 
 // ======================================================================================= K3 scan
@@ -463,22 +536,18 @@ void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, 
 }
 
 // ======================================================================================= K7 state save
-__global__ __launch_bounds__(256) void k_save_state(uint8_t* __restrict__ coded, size_t coded_stride,
-                                                    const uint8_t* __restrict__ il, size_t il_stride,
-                                                    uint8_t* __restrict__ last_group, int fields) {
-    const int c = blockIdx.x;
-    uint32_t* base = reinterpret_cast<uint32_t*>(coded + (size_t)c * coded_stride);
-    const uint32_t* tail = base + (size_t)fields * (kFieldCoded / 4);
-    for (int i = threadIdx.x; i < kTail / 4; i += 256) base[i] = tail[i];  // fields*64584 >= 10608: no overlap
-    if (threadIdx.x < 3) {
-        const uint32_t* lg = reinterpret_cast<const uint32_t*>(il + (size_t)c * il_stride + (size_t)fields * kFieldCoded - 12);
-        reinterpret_cast<uint32_t*>(last_group + (size_t)c * 16)[threadIdx.x] = lg[threadIdx.x];
-    }
+__global__ __launch_bounds__(64) void k_save_state(const uint8_t* __restrict__ il, size_t il_stride,
+                                                   uint8_t* __restrict__ last_group, int channels, int fields) {
+    const int i = blockIdx.x * 64 + threadIdx.x;  // (channel, dword) of the last 12 interleaved bytes
+    const int c = i / 3, w = i - 3 * c;
+    if (c >= channels) return;
+    const uint32_t* lg = reinterpret_cast<const uint32_t*>(il + (size_t)c * il_stride + (size_t)fields * kFieldCoded - 12);
+    reinterpret_cast<uint32_t*>(last_group + (size_t)c * 16)[w] = lg[w];
 }
 
 void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields) {
-    hipLaunchKernelGGL(k_save_state, dim3(channels), dim3(256), 0, s, b.coded, b.coded_stride, b.il, b.il_stride,
-                       b.last_group, fields);
+    hipLaunchKernelGGL(k_save_state, dim3((3 * channels + 63) / 64), dim3(64), 0, s, b.il, b.il_stride, b.last_group,
+                       channels, fields);
 }
 
 // ======================================================================================= K5 mixer + FIR

@@ -50,6 +50,8 @@ typedef struct atsc_hip_config {
 } atsc_hip_config;
 
 #define ATSC_HIP_FLAG_TIMING 1 /* record HIP events around every kernel of a batch (atsc_hip_last_timings) */
+#define ATSC_HIP_FLAG_TAPS 2   /* also materialise the RS-coded byte stream of every batch (atsc_hip_stage_buffer
+                                  ATSC_HIP_STAGE_RAND_RS); the path itself goes TS + parity -> interleaver directly */
 
 /* Stage ids for atsc_hip_stage_buffer / atsc_hip_last_timings. */
 enum {
