@@ -263,22 +263,32 @@ __global__ __launch_bounds__(256) void k_interleave(const uint8_t* __restrict__ 
         const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride) + (size_t)qa * 47;
         const int ndw = (q1 - qa + 1) * 47;
         const int row0 = qa - q0;
-        for (int i0 = 0; i0 < ndw; i0 += 256 * 8) {
-            uint32_t v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + tid + 256 * k;
-                v[k] = i < ndw ? src[i] ^ prbs188[(qa * 47 + i) % (kPackets * 47)] : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int i = i0 + tid + 256 * k;
-                if (i < ndw) s_pkt[row0 * kIlRowDw + i + 6 * (i / 47)] = v[k];
-            }
-        }
         const uint32_t* pp = parity + ((size_t)c * total + qa) * 8;
         const int npar = (q1 - qa + 1) * 5;
-        for (int i = tid; i < npar; i += 256) s_pkt[(row0 + i / 5) * kIlRowDw + 47 + i % 5] = pp[(i / 5) * 8 + i % 5];
+        // every load of the block is issued before the first LDS store: one memory round trip per block
+        constexpr int kLd = (kIlMaxPk * 47 + 255) / 256;   // 39
+        constexpr int kLp = (kIlMaxPk * 5 + 255) / 256;    // 5
+        uint32_t v[kLd], pv[kLp];
+#pragma unroll
+        for (int k = 0; k < kLd; ++k) {
+            const int i = tid + 256 * k;
+            v[k] = i < ndw ? src[i] ^ prbs188[(qa * 47 + i) % (kPackets * 47)] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kLp; ++k) {
+            const int i = tid + 256 * k;
+            pv[k] = i < npar ? pp[(i / 5) * 8 + i % 5] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kLd; ++k) {
+            const int i = tid + 256 * k;
+            if (i < ndw) s_pkt[row0 * kIlRowDw + i + 6 * (i / 47)] = v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < kLp; ++k) {
+            const int i = tid + 256 * k;
+            if (i < npar) s_pkt[(row0 + i / 5) * kIlRowDw + 47 + i % 5] = pv[k];
+        }
     }
     // packets before the batch: coded byte o (-10608 <= o < 0) = tail[10608 + o]
     if (q0 < 0) {
@@ -340,17 +350,15 @@ __global__ __launch_bounds__(256) void k_interleave(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ ts, size_t ts_stride,
                                                    const uint8_t* __restrict__ parity, const uint8_t* __restrict__ prbs,
                                                    uint8_t* __restrict__ tail, int fields) {
-    const int c = blockIdx.x;
+    const int c = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kTail) return;
     const int total = fields * kPackets;
-    const uint8_t* tsc = ts + (size_t)c * ts_stride;
-    const uint8_t* pc = parity + (size_t)c * total * 32;
-    for (int i = threadIdx.x; i < kTail; i += 256) {
-        const int o = total * kSegCoded - kTail + i;   // >= 0: a batch is at least one field
-        const int q = o / kSegCoded, r = o - q * kSegCoded;
-        const uint8_t v = r < 187 ? (uint8_t)(tsc[(size_t)q * kTsBytes + 1 + r] ^ prbs[(q % kPackets) * 187 + r])
-                                  : pc[(size_t)q * 32 + (r - 187)];
-        tail[(size_t)c * kTail + i] = v;
-    }
+    const int o = total * kSegCoded - kTail + i;   // >= 0: a batch is at least one field
+    const int q = o / kSegCoded, r = o - q * kSegCoded;
+    const uint8_t v = r < 187 ? (uint8_t)(ts[(size_t)c * ts_stride + (size_t)q * kTsBytes + 1 + r] ^ prbs[(q % kPackets) * 187 + r])
+                              : parity[((size_t)c * total + q) * 32 + (r - 187)];
+    tail[(size_t)c * kTail + i] = v;
 }
 
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
@@ -359,7 +367,7 @@ void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts
     hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, d_ts, ts_stride, reinterpret_cast<const uint32_t*>(b.parity),
                        b.tail, t.prbs188, b.il, b.il_stride, b.par, fields);
     // the tail is consumed above and replaced by this batch's own (stream order)
-    hipLaunchKernelGGL(k_save_tail, dim3(channels), dim3(256), 0, s, d_ts, ts_stride,
+    hipLaunchKernelGGL(k_save_tail, dim3((kTail + 255) / 256, channels), dim3(256), 0, s, d_ts, ts_stride,
                        reinterpret_cast<const uint8_t*>(b.parity), t.prbs, b.tail, fields);
 }
 

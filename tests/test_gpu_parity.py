@@ -137,6 +137,54 @@ def test_multichannel_and_batch_split(torch_cuda):
     assert np.array_equal(q.view(np.uint32), iq.view(np.uint32)), "batch split changed IQ bits"
 
 
+def test_channel_groups_11_channels(torch_cuda):
+    """11 channels x 2 fields: the FIR walks channels in tasks of 8 and in pairs, so 11 = 8 + 3 exercises a full task,
+    a short task and an odd pair (whose second stream is a dummy); every channel against the oracle."""
+    C_, nf = 11, 2
+    per = [ts_mix(77 + c, nf) for c in range(C_)]
+    enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    sym, iq = run_device(torch_cuda, enc, np.concatenate(per), C_, nf)
+    sym = sym.reshape(C_, -1)
+    iq = iq.reshape(C_, -1)
+    for c in range(C_):
+        want = Oracle().process_fields(per[c], nf, want=("sym", "iq"))
+        assert np.array_equal(sym[c], want["sym"]), f"channel {c}"
+        assert np.abs(iq[c].view(np.float32) - want["iq"]).max() <= IQ_TOL, f"channel {c}"
+
+
+def test_full_size_batch_channel_independence(torch_cuda):
+    """BASELINE config 4 per-GPU shard (64 channels x 64 fields) through a size-independent property: channels are
+    independent and deterministic, so 64 copies of one stream give 64 bit-identical outputs, equal to that stream
+    encoded alone, which is itself checked against the oracle on its first and last fields."""
+    torch = torch_cuda
+    C_, nf = 64, 64
+    one = ts_mt(4321, nf)
+    d_one = torch.from_numpy(one).cuda()
+    d_ts = d_one.repeat(C_).contiguous()
+    enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    n = nf * FIELD_SYMBOLS
+    d_sym = torch.empty(C_ * n, dtype=torch.uint8, device="cuda")
+    d_iq = torch.empty(C_ * n, dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    enc.encode_batch(d_ts.data_ptr(), nf, d_sym.data_ptr(), d_iq.data_ptr(), st)
+    torch.cuda.synchronize()
+    solo = atsc_amd.Encoder(channels=1, max_fields=nf)
+    s_sym = torch.empty(n, dtype=torch.uint8, device="cuda")
+    s_iq = torch.empty(n, dtype=torch.complex64, device="cuda")
+    solo.encode_batch(d_one.data_ptr(), nf, s_sym.data_ptr(), s_iq.data_ptr(), st)
+    torch.cuda.synchronize()
+    sym2 = d_sym.view(C_, n)
+    iq2 = torch.view_as_real(d_iq).view(C_, 2 * n).view(torch.int32)
+    assert bool((sym2 == s_sym.unsqueeze(0)).all()), "channels differ in symbols"
+    assert bool((iq2 == torch.view_as_real(s_iq).view(1, 2 * n).view(torch.int32)).all()), "channels differ in IQ bits"
+    want = Oracle().process_fields(one, nf, want=("sym", "iq"))
+    assert np.array_equal(s_sym.cpu().numpy(), want["sym"])
+    got = torch.view_as_real(s_iq).cpu().numpy().reshape(-1)
+    for f in (0, nf - 1):
+        sl = slice(2 * f * FIELD_SYMBOLS, 2 * (f + 1) * FIELD_SYMBOLS)
+        assert np.abs(got[sl] - want["iq"][sl]).max() <= IQ_TOL
+
+
 def test_streaming_process_api(torch_cuda):
     """atsc_hip_process: arbitrary packet counts, one synchronous in-order callback per field."""
     nf = 6
