@@ -12,6 +12,9 @@
 // All byte/bit stages are bit-exact restatements of the closed forms in SURVEY.md Appendix A; the float
 // stage (fir_fft.hip) follows the reference's rounding for the oscillator recursion.
 #include "kernels.h"
+#ifndef ATSC_ABLATE
+#define ATSC_ABLATE 0
+#endif
 
 
 namespace atsc_k {
@@ -238,111 +241,144 @@ constexpr int kIlSrcBytes = (kIlRows + 204) * 52;    // 42900 coded bytes feed t
 constexpr int kIlGroups = kIlBytes / 12;             // 2691
 constexpr int kIlMaxPk = 210;                        // packets that can overlap 42900 coded bytes
 constexpr int kIlRowDw = 53;
+constexpr int kIlChPerBlock = 8;                     // channels a block walks with its PRBS slice and gather addresses in registers
 
 typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
 
-__global__ __launch_bounds__(256) void k_interleave(const uint8_t* __restrict__ ts, size_t ts_stride,
+__global__ __launch_bounds__(256, 3) void k_interleave(const uint8_t* __restrict__ ts, size_t ts_stride,
                                                     const uint32_t* __restrict__ parity, const uint8_t* __restrict__ tail,
                                                     const uint32_t* __restrict__ prbs188, uint8_t* __restrict__ il,
-                                                    size_t il_stride, uint4* __restrict__ par, int fields) {
+                                                    size_t il_stride, uint4* __restrict__ par, int channels, int fields) {
     __shared__ uint32_t s_pkt[kIlMaxPk * kIlRowDw];  // 44520 B
-    __shared__ uint32_t s_par[13 * 3][32];             // one XOR accumulator per (part, word, lane mod 32): no same-address traffic
+    __shared__ uint32_t s_par[13 * 3][32];           // one XOR accumulator per (part, word, lane mod 32): no same-address traffic
     const int tid = threadIdx.x;
-    const int c = blockIdx.y;
     const int h = blockIdx.x;                          // half-field index within the batch
+    const int c_lo = blockIdx.y * kIlChPerBlock, c_hi = min(channels, c_lo + kIlChPerBlock);
     const int total = fields * kPackets;
     const int o0 = h * kIlBytes - kTail;               // coded offset (batch-relative) of the first byte needed
     const int q0 = (o0 + 52 * kSegCoded) / kSegCoded - 52;  // floor(o0 / 207), o0 >= -10608 > -52*207
     const int q1 = (o0 + kIlSrcBytes - 1) / kSegCoded;      // last packet needed (>= 0, < total)
     const int qa = q0 < 0 ? 0 : q0;                    // first packet that lies in this batch
+    const int ndw = (q1 - qa + 1) * 47;
+    const int npar = (q1 - qa + 1) * 5;
+    const int row0 = qa - q0;
+    constexpr int kLd4 = (kIlMaxPk * 47 + 1023) / 1024;  // 10 x 4 TS dwords per thread
+    constexpr int kLp = (kIlMaxPk * 5 + 255) / 256;    // 5 parity dwords per thread
+    constexpr int kIt = (kIlGroups + 255) / 256;       // 11 groups per thread
 
-    for (int i = tid; i < 13 * 3 * 32; i += 256) (&s_par[0][0])[i] = 0;
-
-    // packets qa..q1 of this batch: TS dwords ^ PRBS (the PRBS repeats every field = 312*47 dwords), then parity
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride) + (size_t)qa * 47;
-        const int ndw = (q1 - qa + 1) * 47;
-        const int row0 = qa - q0;
-        const uint32_t* pp = parity + ((size_t)c * total + qa) * 8;
-        const int npar = (q1 - qa + 1) * 5;
-        // every load of the block is issued before the first LDS store: one memory round trip per block
-        constexpr int kLd = (kIlMaxPk * 47 + 255) / 256;   // 39
-        constexpr int kLp = (kIlMaxPk * 5 + 255) / 256;    // 5
-        uint32_t v[kLd], pv[kLp];
+    // The PRBS slice of the staged packets does not depend on the channel (it repeats every field = 312*47 dwords):
+    // read once per block, kept in registers.
+    uint32_t prbs[kLd4][4];
 #pragma unroll
-        for (int k = 0; k < kLd; ++k) {
-            const int i = tid + 256 * k;
-            v[k] = i < ndw ? src[i] ^ prbs188[(qa * 47 + i) % (kPackets * 47)] : 0u;
-        }
+    for (int k = 0; k < kLd4; ++k)
 #pragma unroll
-        for (int k = 0; k < kLp; ++k) {
-            const int i = tid + 256 * k;
-            pv[k] = i < npar ? pp[(i / 5) * 8 + i % 5] : 0u;
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * (tid + 256 * k) + j;
+            prbs[k][j] = i < ndw ? prbs188[(qa * 47 + i) % (kPackets * 47)] : 0u;
         }
-#pragma unroll
-        for (int k = 0; k < kLd; ++k) {
-            const int i = tid + 256 * k;
-            if (i < ndw) s_pkt[row0 * kIlRowDw + i + 6 * (i / 47)] = v[k];
-        }
-#pragma unroll
-        for (int k = 0; k < kLp; ++k) {
-            const int i = tid + 256 * k;
-            if (i < npar) s_pkt[(row0 + i / 5) * kIlRowDw + 47 + i % 5] = pv[k];
-        }
-    }
-    // packets before the batch: coded byte o (-10608 <= o < 0) = tail[10608 + o]
-    if (q0 < 0) {
-        const uint8_t* tl = tail + (size_t)c * kTail;
-        uint8_t* s8w = reinterpret_cast<uint8_t*>(s_pkt);
-        for (int i = tid; i < kTail; i += 256) {
-            const int q = (i + (52 * kSegCoded - kTail)) / kSegCoded - 52;  // floor((i - 10608) / 207)
-            const int r = i - kTail - q * kSegCoded;
-            s8w[(q - q0) * (kIlRowDw * 4) + 1 + r] = tl[i];
-        }
-    }
-    __syncthreads();
-
-    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_pkt);
-    uint8_t* dst = il + (size_t)c * il_stride + (size_t)h * kIlBytes;
     const int g_field0 = (h & 1) * kIlGroups;          // group index of this block's first group within its field
-    for (int g = tid; g < kIlGroups; g += 256) {
-        uint32_t dw[3];
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_pkt);
+
+    for (int c = c_lo; c < c_hi; ++c) {
+        // index math is redone per channel on purpose (opaque copy of tid): hoisted out of the loop it costs ~100 registers
+        int tid_c = tid;
+        asm volatile("" : "+v"(tid_c));
+        for (int i = tid; i < 13 * 3 * 32; i += 256) (&s_par[0][0])[i] = 0;
+        // packets qa..q1 of this batch: TS dwords ^ PRBS, then parity; every load is issued before the first LDS store
+        {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride) + (size_t)qa * 47;
+            const uint32_t* pp = parity + ((size_t)c * total + qa) * 8;
+            u32x4a4 v[kLd4];
+            uint32_t pv[kLp];
+            const int ndw4 = ndw & ~3;                   // ndw is a multiple of 47; the last 0..3 dwords go one by one
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-            const int d = 3 * g + w;
-            const int a = d / 13;
-            const int r = 4 * (d - 13 * a);
-            const int abs0 = o0 + (a + 204 - 4 * r) * 52 + r;        // coded offset of byte 0; byte j sits 207*j earlier
-            const int q = (abs0 + 52 * kSegCoded) / kSegCoded - 52;   // floor
-            const int addr = (q - q0) * (kIlRowDw * 4) + 1 + (abs0 - q * kSegCoded);
-            dw[w] = (uint32_t)s8[addr] | ((uint32_t)s8[addr - kIlRowDw * 4] << 8) |
-                    ((uint32_t)s8[addr - 2 * kIlRowDw * 4] << 16) | ((uint32_t)s8[addr - 3 * kIlRowDw * 4] << 24);
+            for (int k = 0; k < kLd4; ++k) {
+                const int i = 4 * (tid_c + 256 * k);
+                if (i < ndw4) v[k] = *reinterpret_cast<const u32x4a4*>(src + i);
+                else {
+                    v[k].x = i < ndw ? src[i] : 0u;
+                    v[k].y = i + 1 < ndw ? src[i + 1] : 0u;
+                    v[k].z = i + 2 < ndw ? src[i + 2] : 0u;
+                    v[k].w = 0u;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kLp; ++k) {
+                const int i = tid_c + 256 * k;
+                pv[k] = i < npar ? pp[(i / 5) * 8 + i % 5] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < kLd4; ++k) {
+                const uint32_t vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 4 * (tid_c + 256 * k) + j;
+                    if (i < ndw) s_pkt[row0 * kIlRowDw + i + 6 * (i / 47)] = vv[j] ^ prbs[k][j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kLp; ++k) {
+                const int i = tid_c + 256 * k;
+                if (i < npar) s_pkt[(row0 + i / 5) * kIlRowDw + 47 + i % 5] = pv[k];
+            }
         }
-        u32x3a4 o3;
-        o3.x = dw[0]; o3.y = dw[1]; o3.z = dw[2];
-        *reinterpret_cast<u32x3a4*>(dst + 12 * g) = o3;
-        // parities of this byte-time for the 12 encoders
-        const Words3 e = canonical_group(dw, g_field0 + g);
-        const int p = g / kPartGroups;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            uint32_t z2, z0, pr;
-            trellis_local(e.w[k], z2, z0, pr);
-            atomicXor(&s_par[3 * p + k][tid & 31], pr);
+        // packets before the batch: coded byte o (-10608 <= o < 0) = tail[10608 + o]
+        if (q0 < 0) {
+            const uint8_t* tl = tail + (size_t)c * kTail;
+            uint8_t* s8w = reinterpret_cast<uint8_t*>(s_pkt);
+            for (int i = tid; i < kTail; i += 256) {
+                const int q = (i + (52 * kSegCoded - kTail)) / kSegCoded - 52;  // floor((i - 10608) / 207)
+                const int r = i - kTail - q * kSegCoded;
+                s8w[(q - q0) * (kIlRowDw * 4) + 1 + r] = tl[i];
+            }
         }
-    }
-    __syncthreads();
-    if (tid < 13 * 3) {  // fold the 32 slots (rotated start: conflict-free), then one uint4 per part
-        uint32_t v = 0;
+        __syncthreads();
+
+        uint8_t* dst = il + (size_t)c * il_stride + (size_t)h * kIlBytes;
+#pragma unroll 1
+        for (int it = 0; it < kIt; ++it) {
+            const int g = tid_c + 256 * it;
+            if (g < kIlGroups) {
+                uint32_t dw[3];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) v ^= s_par[tid][(i + tid) & 31];
-        s_par[tid][0] = v;
-    }
-    __syncthreads();
-    if (tid < 13) {
-        const int f = h >> 1;
-        par[((size_t)c * fields + f) * kParts + (h & 1) * 13 + tid] =
-            make_uint4(s_par[3 * tid][0], s_par[3 * tid + 1][0], s_par[3 * tid + 2][0], 0);
+                for (int w = 0; w < 3; ++w) {
+                    const int d = 3 * g + w;
+                    const int a = d / 13;
+                    const int r = 4 * (d - 13 * a);
+                    const int abs0 = o0 + (a + 204 - 4 * r) * 52 + r;        // coded offset of byte 0; byte j sits 207*j earlier
+                    const int q = (abs0 + 52 * kSegCoded) / kSegCoded - 52;   // floor
+                    const int addr = (q - q0) * (kIlRowDw * 4) + 1 + (abs0 - q * kSegCoded);
+                    dw[w] = (uint32_t)s8[addr] | ((uint32_t)s8[addr - kIlRowDw * 4] << 8) |
+                            ((uint32_t)s8[addr - 2 * kIlRowDw * 4] << 16) | ((uint32_t)s8[addr - 3 * kIlRowDw * 4] << 24);
+                }
+                u32x3a4 o3;
+                o3.x = dw[0]; o3.y = dw[1]; o3.z = dw[2];
+                *reinterpret_cast<u32x3a4*>(dst + 12 * g) = o3;
+                // parities of this byte-time for the 12 encoders
+                const Words3 e = canonical_group(dw, g_field0 + g);
+                const int p = g / kPartGroups;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    uint32_t z2, z0, pr;
+                    trellis_local(e.w[k], z2, z0, pr);
+                    atomicXor(&s_par[3 * p + k][tid & 31], pr);
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 13 * 3) {  // fold the 32 slots (rotated start: conflict-free), then one uint4 per part
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) v ^= s_par[tid][(i + tid) & 31];
+            s_par[tid][0] = v;
+        }
+        __syncthreads();
+        if (tid < 13) {
+            const int f = h >> 1;
+            par[((size_t)c * fields + f) * kParts + (h & 1) * 13 + tid] =
+                make_uint4(s_par[3 * tid][0], s_par[3 * tid + 1][0], s_par[3 * tid + 2][0], 0);
+        }
+        __syncthreads();  // s_pkt and s_par are rewritten for the next channel
     }
 }
 
@@ -363,9 +399,9 @@ __global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ t
 
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                        int channels, int fields) {
-    dim3 grid(2 * fields, channels);
+    dim3 grid(2 * fields, (channels + kIlChPerBlock - 1) / kIlChPerBlock);
     hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, d_ts, ts_stride, reinterpret_cast<const uint32_t*>(b.parity),
-                       b.tail, t.prbs188, b.il, b.il_stride, b.par, fields);
+                       b.tail, t.prbs188, b.il, b.il_stride, b.par, channels, fields);
     // the tail is consumed above and replaced by this batch's own (stream order)
     hipLaunchKernelGGL(k_save_tail, dim3((kTail + 255) / 256, channels), dim3(256), 0, s, d_ts, ts_stride,
                        reinterpret_cast<const uint8_t*>(b.parity), t.prbs, b.tail, fields);
