@@ -416,9 +416,19 @@ void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, floa
 
 void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
                         float2* osc_tab, int channels, int fields) {
-    // tasks of 8 channels: small enough that the flat task list balances over 256 CUs (>= 36 rounds at 64 x 64)
-    static const int cpg_env = [] { const char* e = getenv("ATSC_FIR_CH_PER_TASK"); return e ? atoi(e) : 8; }();
-    const int ch_per_group = channels < cpg_env ? channels : cpg_env;
+    // Channels per task: as many as possible (the oscillator slice of a task is read once and shared by its channels),
+    // but at least ~8 rounds of tasks over the 4096 half-wave slots of the chip so that the flat task list balances.
+    static const int cpg_env = [] { const char* e = getenv("ATSC_FIR_CH_PER_TASK"); return e ? atoi(e) : 0; }();
+    int ch_per_group = cpg_env;
+    if (ch_per_group <= 0) {
+        const long per_group = (long)kFftBlocks * fields;           // tasks per channel group
+        const long groups = (8L * 4096 + per_group - 1) / per_group;   // groups wanted
+        ch_per_group = (int)(channels / (groups < 1 ? 1 : groups));
+        ch_per_group &= ~1;                                          // whole pairs
+        if (ch_per_group > 32) ch_per_group = 32;
+        if (ch_per_group < 2) ch_per_group = 2;
+    }
+    if (ch_per_group > channels) ch_per_group = channels;
     const int ch_groups = (channels + ch_per_group - 1) / ch_per_group;
     const long tasks = (long)kFftBlocks * ch_groups * fields;
     const unsigned grid = (unsigned)((tasks + kHalfWaves - 1) / kHalfWaves);

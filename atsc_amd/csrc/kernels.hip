@@ -12,6 +12,8 @@
 // All byte/bit stages are bit-exact restatements of the closed forms in SURVEY.md Appendix A; the float
 // stage (fir_fft.hip) follows the reference's rounding for the oscillator recursion.
 #include "kernels.h"
+
+#include <cstdlib>
 #ifndef ATSC_ABLATE
 #define ATSC_ABLATE 0
 #endif
@@ -241,19 +243,20 @@ constexpr int kIlSrcBytes = (kIlRows + 204) * 52;    // 42900 coded bytes feed t
 constexpr int kIlGroups = kIlBytes / 12;             // 2691
 constexpr int kIlMaxPk = 210;                        // packets that can overlap 42900 coded bytes
 constexpr int kIlRowDw = 53;
-constexpr int kIlChPerBlock = 8;                     // channels a block walks with its PRBS slice and gather addresses in registers
+constexpr int kIlChPerBlock = 4;                     // channels a block walks with its PRBS slice and gather addresses in registers
 
 typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
 
 __global__ __launch_bounds__(256, 3) void k_interleave(const uint8_t* __restrict__ ts, size_t ts_stride,
                                                     const uint32_t* __restrict__ parity, const uint8_t* __restrict__ tail,
                                                     const uint32_t* __restrict__ prbs188, uint8_t* __restrict__ il,
-                                                    size_t il_stride, uint4* __restrict__ par, int channels, int fields) {
+                                                    size_t il_stride, uint4* __restrict__ par, int channels, int fields,
+                                                    int ch_per_block) {
     __shared__ uint32_t s_pkt[kIlMaxPk * kIlRowDw];  // 44520 B
     __shared__ uint32_t s_par[13 * 3][32];           // one XOR accumulator per (part, word, lane mod 32): no same-address traffic
     const int tid = threadIdx.x;
     const int h = blockIdx.x;                          // half-field index within the batch
-    const int c_lo = blockIdx.y * kIlChPerBlock, c_hi = min(channels, c_lo + kIlChPerBlock);
+    const int c_lo = blockIdx.y * ch_per_block, c_hi = min(channels, c_lo + ch_per_block);
     const int total = fields * kPackets;
     const int o0 = h * kIlBytes - kTail;               // coded offset (batch-relative) of the first byte needed
     const int q0 = (o0 + 52 * kSegCoded) / kSegCoded - 52;  // floor(o0 / 207), o0 >= -10608 > -52*207
@@ -399,9 +402,11 @@ __global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ t
 
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                        int channels, int fields) {
-    dim3 grid(2 * fields, (channels + kIlChPerBlock - 1) / kIlChPerBlock);
+    static const int cpb_env = [] { const char* e = getenv("ATSC_IL_CH_PER_BLOCK"); return e ? atoi(e) : kIlChPerBlock; }();
+    const int cpb = cpb_env < 1 ? 1 : cpb_env;
+    dim3 grid(2 * fields, (channels + cpb - 1) / cpb);
     hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, d_ts, ts_stride, reinterpret_cast<const uint32_t*>(b.parity),
-                       b.tail, t.prbs188, b.il, b.il_stride, b.par, channels, fields);
+                       b.tail, t.prbs188, b.il, b.il_stride, b.par, channels, fields, cpb);
     // the tail is consumed above and replaced by this batch's own (stream order)
     hipLaunchKernelGGL(k_save_tail, dim3((kTail + 255) / 256, channels), dim3(256), 0, s, d_ts, ts_stride,
                        reinterpret_cast<const uint8_t*>(b.parity), t.prbs, b.tail, fields);
