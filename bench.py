@@ -148,6 +148,14 @@ def main():
     fir_s = stage_ms["mix_fir"] / 1e3
     fir_gbs = FIR_BYTES_PER_SYM * sym_per_step_gpu / fir_s / 1e9
 
+    # the other stages against the same roof, with SURVEY 8(d)'s algorithmic bytes per field
+    alg_bytes_field = {"rand_rs": 58656 + 64584, "interleave": 2 * 64584, "trellis_map": 64584 + 260416}
+    stages_roofline = {}
+    for k, bpf in alg_bytes_field.items():
+        gbs = bpf * C_ * F / (stage_ms[k] / 1e3) / 1e9 if stage_ms[k] > 0 else 0.0
+        stages_roofline[k] = {"algorithmic_bytes_per_launch": bpf * C_ * F, "avg_launch_ms": round(stage_ms[k], 4),
+                              "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+
     # HBM bytes per launch of the FIR kernel from the committed PMC passes (same workload only)
     traffic = None
     try:
@@ -191,6 +199,7 @@ def main():
                     "PMC traffic per launch: profiles/",
             "whole_chain_gbs": round(CHAIN_BYTES_PER_SYM * msym_s * 1e6 / world / 1e9, 1),
         },
+        "roofline_other_stages": stages_roofline,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
