@@ -1,0 +1,109 @@
+"""Loop-back verifier (TEST INFRASTRUCTURE ONLY): 8-level symbols -> TS bytes, written from the A/53 definitions and
+independent of both the oracle and the product tables.
+
+The modulator's byte/bit stages are invertible without noise: symbol demap -> inverse precoder -> byte assembly ->
+trellis de-commutation -> convolutional de-interleave -> RS syndrome check -> de-randomize.  It gives a
+size-independent property for full-size batches: decode(encode(ts)) == ts and every RS(207,187)
+codeword has zero syndromes.  All steps are torch gathers / XORs, so the check runs on the GPU next to the encoder
+(or on the CPU for small cases).
+
+Conventions: data symbol j of data segment s comes from encoder (4s+j) mod 12, symbol number
+t = 69s + j//12 of that encoder in the field; a byte is four (x2,x1) pairs MSB first; Z2[t] = x2[t] ^ Z2[t-1], Z1 = x1;
+encoder e takes, as its g-th byte of the field, IL[12g + ((e - 4*((12g//207) % 3)) mod 12)]; IL[M] = E[M - 208*(M mod 52)].
+"""
+import numpy as np
+import torch
+
+SEGS, SEG_SYMS, DATA_PER_SEG = 313, 832, 828
+FIELD_SYMS = SEGS * SEG_SYMS
+FIELD_CODED = 312 * 207
+ENC_SYMS = 312 * 828 // 12          # 21528 symbols per encoder per field
+ENC_BYTES = ENC_SYMS // 4           # 5382
+TAIL = 208 * 51                     # coded bytes of a field that only the next field's symbols carry
+
+
+def _prbs():
+    """Randomizer bytes for one field (187 per packet, restart every field): 16-bit LFSR, preset 0xF180."""
+    st = 0xF180
+    out = np.empty(312 * 187, np.uint8)
+    for i in range(out.size):
+        out[i] = ((st & 0x3C00) >> 6) | ((st & 0x40) >> 3) | ((st & 0xC) >> 1) | (st & 1)
+        st <<= 1
+        if st & 0x10000:
+            st ^= (0x9C65 << 1) | 1
+    return out
+
+
+def _gf_tables():
+    exp = np.zeros(512, np.int64)
+    log = np.zeros(256, np.int64)
+    v = 1
+    for i in range(255):
+        exp[i] = exp[i + 255] = v
+        log[v] = i
+        v = (v << 1) ^ (0x11D if v & 0x80 else 0)
+    return exp, log
+
+
+def _perms():
+    s = np.arange(312)[:, None]
+    j = np.arange(828)[None, :]
+    e = (4 * s + j) % 12
+    t = 69 * s + j // 12
+    sym_of = np.empty((12, ENC_SYMS), np.int64)       # (encoder, symbol number) -> data-symbol index s*828+j
+    sym_of[e, t] = s * 828 + j
+    g = np.arange(ENC_BYTES)[None, :]
+    enc = np.arange(12)[:, None]
+    shift = 4 * ((12 * g // 207) % 3)
+    il_of = 12 * g + (enc - shift) % 12               # (encoder, byte number) -> interleaved byte index in the field
+    return sym_of, il_of
+
+
+_CACHE = {}
+
+
+def _consts(device):
+    key = str(device)
+    if key not in _CACHE:
+        sym_of, il_of = _perms()
+        exp, log = _gf_tables()
+        _CACHE[key] = dict(sym_of=torch.from_numpy(sym_of.reshape(-1)).to(device),
+                           il_of=torch.from_numpy(il_of.reshape(-1)).to(device),
+                           prbs=torch.from_numpy(_prbs().reshape(312, 187)).to(device),
+                           exp=torch.from_numpy(exp).to(device), log=torch.from_numpy(log).to(device))
+    return _CACHE[key]
+
+
+def decode_symbols(sym, fields):
+    """sym: uint8 tensor [fields*260416] of level indices 0..7 of ONE stream from its first field on.
+    Returns (ts_payload [(fields-1)*312, 187] uint8, worst_syndrome int): the de-randomized packet payloads (TS bytes
+    1..187 of every packet) of all fields but the last (its tail lives in symbols of the next field), and the OR of all
+    RS syndromes of those codewords (0 = every codeword valid)."""
+    k = _consts(sym.device)
+    F = fields
+    v = sym.view(F, SEGS, SEG_SYMS)[:, 1:, 4:].reshape(F, 312 * 828).long()
+    v = v[:, k["sym_of"]].view(F, 12, ENC_SYMS).permute(1, 0, 2).reshape(12, F * ENC_SYMS)  # per encoder, time order
+    z2 = v >> 2
+    x2 = z2.clone()
+    x2[:, 1:] ^= z2[:, :-1]                                   # Z2[-1] = 0 at stream start
+    pair = ((x2 << 1) | ((v >> 1) & 1)).view(12, F * ENC_BYTES, 4)
+    byts = (pair[..., 0] << 6) | (pair[..., 1] << 4) | (pair[..., 2] << 2) | pair[..., 3]
+    il = torch.empty(F, FIELD_CODED, dtype=torch.long, device=sym.device)
+    il[:, k["il_of"]] = byts.view(12, F, ENC_BYTES).permute(1, 0, 2).reshape(F, 12 * ENC_BYTES)
+    il = il.view(-1)
+    n = torch.arange((F - 1) * FIELD_CODED, device=sym.device)
+    coded = il[n + 208 * (n % 52)].view((F - 1) * 312, 207)
+    # RS(207,187), generator roots alpha^0..alpha^19: S_i = sum_k c[k] * alpha^(i*(206-k)) must vanish
+    lg = k["log"][coded]
+    nz = coded != 0
+    pw = (206 - torch.arange(207, device=sym.device))[None, :]
+    worst = 0
+    for i in range(20):
+        term = torch.where(nz, k["exp"][(lg + i * pw) % 255], torch.zeros_like(coded))
+        s = torch.zeros(coded.shape[0], dtype=torch.long, device=sym.device)
+        for b in range(8):
+            s |= (((term >> b) & 1).sum(dim=1) & 1) << b
+        worst |= int(s.max().item())
+    rows = torch.arange((F - 1) * 312, device=sym.device) % 312
+    payload = (coded[:, :187] ^ k["prbs"][rows].long()).to(torch.uint8)
+    return payload, worst

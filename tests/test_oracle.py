@@ -110,3 +110,21 @@ def test_reference_api_chunking(golden):
     n2, iq2 = r.process(ts[1000 * 188:], 4 * 312 - 1000, 8)
     assert (n1, n2) == (3, 1)
     assert sha(np.concatenate([iq1, iq2])) == g["cases"]["mt1234_4"]["sha256"]["iq"]
+
+
+def test_loopback_decoder_inverts_the_oracle():
+    """tests/loopback.py (independent symbol -> TS decoder) recovers the TS payload from the oracle's symbols and finds
+    every RS codeword valid; a corrupted symbol is noticed.  Pins the verifier that the full-size GPU test relies on."""
+    import torch
+    from loopback import decode_symbols
+    nf = 3
+    ts = ts_mix(99, nf)
+    sym = Oracle().process_fields(ts, nf, want=("sym",))["sym"]
+    payload, worst = decode_symbols(torch.from_numpy(sym.copy()), nf)
+    want = ts.reshape(nf * 312, 188)[:(nf - 1) * 312, 1:]
+    assert worst == 0
+    assert np.array_equal(payload.numpy(), want)
+    bad = sym.copy()
+    bad[FIELD_SYMS + 5 * 832 + 4 + 100] ^= 4   # flip Z2 of one data symbol of field 1 (early symbols of field 0 carry pre-stream bytes)
+    payload2, worst2 = decode_symbols(torch.from_numpy(bad), nf)
+    assert worst2 != 0 and not np.array_equal(payload2.numpy(), want)
