@@ -331,12 +331,10 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         v2f xa[32], xb[32];
         // ---- symbols of both streams through LDS, next pair's symbols prefetched
         stage_syms(xs, t, a_lo, a_hi);
+        stage_syms(xs + 128, t, b_lo, b_hi);   // 1 KB further on: one LDS round trip for both streams
         wave_lds_sync();
         mix(xa, xs, t, o);
-        wave_lds_sync();
-        stage_syms(xs, t, b_lo, b_hi);
-        wave_lds_sync();
-        mix(xb, xs, t, o);
+        mix(xb, xs + 128, t, o);
         wave_lds_sync();
         {
             const int ca = min(c + 2, c_hi - 1), cb = min(c + 3, c_hi - 1);
