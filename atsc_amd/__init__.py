@@ -35,7 +35,8 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
            "atsc_hip_encode_begin", "atsc_hip_encode_finish",
            "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_export_state", "atsc_hip_import_state",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
-           "atsc_hip_batch_timings", "atsc_hip_get_table",
+           "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes",
+           "atsc_hip_process_chunked",
            "atsc_hip_error_string", "atsc_hip_version")
 
 
@@ -54,6 +55,8 @@ class StreamState(C.Structure):
 
 
 FIELD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint)
+CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
+IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
 
 _lib = None
 
@@ -93,6 +96,10 @@ def load_library():
     L.atsc_hip_timing_reserve.argtypes = [vp, C.c_int]
     L.atsc_hip_batch_timings.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.atsc_hip_get_table.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.atsc_hip_set_iq_format.argtypes = [vp, C.c_int]
+    L.atsc_hip_iq_sample_bytes.argtypes = [C.c_int]
+    L.atsc_hip_iq_sample_bytes.restype = C.c_size_t
+    L.atsc_hip_process_chunked.argtypes = [vp, u8p, C.c_uint, C.c_size_t, CHUNK_CB, vp]
     L.atsc_hip_error_string.argtypes = [C.c_int]
     L.atsc_hip_error_string.restype = C.c_char_p
     L.atsc_hip_version.restype = C.c_char_p
@@ -139,6 +146,17 @@ class Encoder:
         assert buf.size >= count * TS_PACKET_BYTES
         cb = FIELD_CB(lambda user, iq, nbytes: fn(iq, nbytes))
         check(self.L.atsc_hip_process(self.h, buf.ctypes.data, count, cb, None))
+
+    def process_chunked(self, pkts, count, mtu_samples, fn):
+        """SDR-sink shape (util/atsc_encoder.cpp:84-100): fn(ptr:int, nsamples:int, fmt:int) per <= mtu piece of a field."""
+        import numpy as np
+        buf = np.ascontiguousarray(np.frombuffer(pkts, dtype=np.uint8) if not isinstance(pkts, np.ndarray) else pkts)
+        assert buf.size >= count * TS_PACKET_BYTES
+        cb = CHUNK_CB(lambda user, p, n, fmt: fn(p, n, fmt))
+        check(self.L.atsc_hip_process_chunked(self.h, buf.ctypes.data, count, mtu_samples, cb, None))
+
+    def set_iq_format(self, fmt):
+        check(self.L.atsc_hip_set_iq_format(self.h, fmt))
 
     # ---- batched device path
     def encode_batch(self, d_ts, fields, d_sym=None, d_iq=None, stream=None):

@@ -41,6 +41,7 @@ struct atsc_hip_encoder {
     uint64_t field_index = 0;
     int pending_fields = 0;    // fields of a batch between encode_begin and encode_finish
     int last_fields = 0;       // field count of the last batch (internal symbol buffer is packed with it)
+    int iq_format = ATSC_HIP_IQ_CF32;
     void* d_tables = nullptr;
 
     // streaming path (1 channel)
@@ -239,8 +240,7 @@ int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, vo
     if (d_iq) {
         launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields);
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
-        launch_mix_fir_fft(s, d_sym, sym_stride, static_cast<float2*>(d_iq), (size_t)fields * kFieldSyms, e->d_osc_tab, C,
-                           fields);
+        launch_mix_fir_fft(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms, e->d_osc_tab, C, fields, e->iq_format);
     } else {
         launch_osc_advance(s, oin, oout, e->scale, (unsigned)fields);
     }
@@ -332,32 +332,53 @@ extern "C" int atsc_hip_encode_batch_host(atsc_hip_encoder* e, const uint8_t* h_
     void* d_iq = nullptr;
     HIP_TRY(hipMalloc(&d_ts, ts_bytes));
     int rc = static_cast<int>(hipMemcpy(d_ts, h_ts, ts_bytes, hipMemcpyHostToDevice));
-    if (!rc && h_iq) rc = static_cast<int>(hipMalloc(&d_iq, sym_bytes * 8));
+    const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
+    if (!rc && h_iq) rc = static_cast<int>(hipMalloc(&d_iq, sym_bytes * ss));
     if (!rc) rc = atsc_hip_encode_batch(e, d_ts, fields, nullptr, d_iq, nullptr);
     if (!rc) rc = static_cast<int>(hipDeviceSynchronize());
     if (!rc && h_sym) {
         // internal symbol buffer is packed with the batch's own field count
         rc = static_cast<int>(hipMemcpy(h_sym, e->d_sym, sym_bytes, hipMemcpyDeviceToHost));
     }
-    if (!rc && h_iq) rc = static_cast<int>(hipMemcpy(h_iq, d_iq, sym_bytes * 8, hipMemcpyDeviceToHost));
+    if (!rc && h_iq) rc = static_cast<int>(hipMemcpy(h_iq, d_iq, sym_bytes * ss, hipMemcpyDeviceToHost));
     hipFree(d_ts);
     hipFree(d_iq);
     return rc;
 }
 
-// Streaming path: reference semantics of atsc_encoder_impl::process (atsc.cpp:59-77).
-extern "C" int atsc_hip_process(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb,
-                                void* user) {
+extern "C" size_t atsc_hip_iq_sample_bytes(int format) {
+    switch (format) {
+        case ATSC_HIP_IQ_CF32: return 8;
+        case ATSC_HIP_IQ_CS16: return 4;
+        case ATSC_HIP_IQ_CS8: return 2;
+        default: return 0;
+    }
+}
+
+extern "C" int atsc_hip_set_iq_format(atsc_hip_encoder* e, int format) {
+    if (!e || !atsc_hip_iq_sample_bytes(format)) return ATSC_HIP_ERR_ARG;
+    if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    e->iq_format = format;
+    return ATSC_HIP_OK;
+}
+
+// Streaming path: reference semantics of atsc_encoder_impl::process (atsc.cpp:59-77).  With mtu_samples > 0 every
+// field is handed out in pieces of at most mtu_samples, never spanning a field (util/atsc_encoder.cpp:90-99).
+static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb,
+                        atsc_hip_chunk_cb chunk_cb, size_t mtu_samples, void* user) {
     if (!e || (!h_pkts && count)) return ATSC_HIP_ERR_ARG;
     if (e->cfg.channels != 1) return ATSC_HIP_ERR_STATE;
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t F = e->cfg.max_fields;
     if (!e->d_ts) {
+        // sized for CF32, the largest sample format
         HIP_TRY(hipMalloc(&e->d_ts, F * kFieldTs));
         HIP_TRY(hipMalloc(&e->d_iq, F * kFieldSyms * sizeof(float2)));
         HIP_TRY(hipHostMalloc(&e->h_ts_pinned, F * kFieldTs, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&e->h_iq_pinned, F * kFieldSyms * sizeof(float2), hipHostMallocDefault));
     }
+    const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
+    const size_t field_bytes = (size_t)kFieldSyms * ss;
     // copy-before-return contract (atsc.cpp:66)
     e->pending.insert(e->pending.end(), h_pkts, h_pkts + (size_t)count * ATSC_HIP_TS_PACKET_BYTES);
     size_t done = 0;
@@ -367,15 +388,36 @@ extern "C" int atsc_hip_process(atsc_hip_encoder* e, const uint8_t* h_pkts, unsi
         HIP_TRY(hipMemcpyAsync(e->d_ts, e->h_ts_pinned, (size_t)nf * kFieldTs, hipMemcpyHostToDevice, nullptr));
         int rc = atsc_hip_encode_batch(e, e->d_ts, nf, nullptr, e->d_iq, nullptr);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(e->h_iq_pinned, e->d_iq, (size_t)nf * kFieldSyms * sizeof(float2), hipMemcpyDeviceToHost,
-                               nullptr));
+        HIP_TRY(hipMemcpyAsync(e->h_iq_pinned, e->d_iq, (size_t)nf * field_bytes, hipMemcpyDeviceToHost, nullptr));
         HIP_TRY(hipStreamSynchronize(nullptr));
         done += (size_t)nf * kFieldTs;
-        if (cb)
-            for (int f = 0; f < nf; ++f) cb(user, e->h_iq_pinned + (size_t)f * kFieldSyms, ATSC_HIP_FIELD_IQ_BYTES);
+        auto* base = reinterpret_cast<uint8_t*>(e->h_iq_pinned);
+        for (int f = 0; f < nf; ++f) {
+            uint8_t* field = base + (size_t)f * field_bytes;
+            if (cb) cb(user, field, (unsigned)field_bytes);
+            if (chunk_cb) {
+                size_t remaining = kFieldSyms;
+                while (remaining > 0) {
+                    const size_t n = std::min(remaining, mtu_samples);
+                    chunk_cb(user, field + ((size_t)kFieldSyms - remaining) * ss, n, e->iq_format);
+                    remaining -= n;
+                }
+            }
+        }
     }
     e->pending.erase(e->pending.begin(), e->pending.begin() + done);
     return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_process(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb,
+                                void* user) {
+    return process_impl(e, h_pkts, count, cb, nullptr, 0, user);
+}
+
+extern "C" int atsc_hip_process_chunked(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned count, size_t mtu_samples,
+                                        atsc_hip_chunk_cb cb, void* user) {
+    if (!mtu_samples || !cb) return ATSC_HIP_ERR_ARG;
+    return process_impl(e, h_pkts, count, nullptr, cb, mtu_samples, user);
 }
 
 extern "C" int atsc_hip_export_state(atsc_hip_encoder* e, int channel, atsc_hip_stream_state* out) {

@@ -248,20 +248,47 @@ __device__ __forceinline__ void pass2_spectrum(v2f (&x)[32], const float4* hs) {
 #pragma unroll
     for (int p = 0; p < 32; ++p) x[p] = y[p];
 }
+// ---- output sample formats (SDR sink adapter; the reference only ever hands out CF32,
+// util/atsc_encoder.cpp:75).  CS16 / CS8 are the SoapySDR-style fixed-point formats, full scale 1.0 <-> 32767 / 127:
+//   q = rint(clamp(y, -1, 1) * 32767)   (round half to even of the exact product; one v_cvt_pknorm_i16_f32)
+//   q = rint(clamp(y, -1, 1) * 127)     (fma onto 1.5*2^23: the integer lands in the low mantissa bits)
+template <int FMT> struct OutSample;
+template <> struct OutSample<kIqCf32> { typedef float2 type; };
+template <> struct OutSample<kIqCs16> { typedef uint32_t type; };
+template <> struct OutSample<kIqCs8>  { typedef uint16_t type; };
+
+template <int FMT>
+__device__ __forceinline__ typename OutSample<FMT>::type to_out(v2f y) {
+    if constexpr (FMT == kIqCf32) {
+        return make_float2(y.x, y.y);
+    } else if constexpr (FMT == kIqCs16) {
+        uint32_t r;
+        asm("v_cvt_pknorm_i16_f32 %0, %1, %2" : "=v"(r) : "v"(y.x), "v"(y.y));
+        return r;
+    } else {
+        const float re = __builtin_amdgcn_fmed3f(y.x, -1.0f, 1.0f), im = __builtin_amdgcn_fmed3f(y.y, -1.0f, 1.0f);
+        const v2f m = vfma((v2f){re, im}, (v2f){127.0f, 127.0f}, (v2f){12582912.0f, 12582912.0f});
+        // bytes: low byte of re's bits, low byte of im's bits
+        return (uint16_t)__builtin_amdgcn_perm(__float_as_uint(m.y), __float_as_uint(m.x), 0x0c0c0400u);
+    }
+}
+
 // inverse pass 2 (over kA) -> y[t + 32*nA]; rows nA < 28 are free of circular wrap.  Rows leave as soon as the last
 // butterfly stage has produced them.  dst_lo serves rows 0..17, dst_hi rows 18..27 (a trash area for the last block
 // of a field, which has only 18 rows): always 28 stores, so every vmcnt wait in the loop is exact.
-__device__ __forceinline__ void pass4_store(v2f (&y)[32], float2* dst_lo, float2* dst_hi) {
+template <int FMT>
+__device__ __forceinline__ void pass4_store(v2f (&y)[32], typename OutSample<FMT>::type* dst_lo,
+                                            typename OutSample<FMT>::type* dst_hi) {
 #if ATSC_ABLATE & 1
     fft32<true>(y);
 #pragma unroll
     for (int n = 0; n < kFftValid / 32; ++n) asm volatile("" ::"v"(y[n]));
-    if (y[0].x == 123.456f) dst_lo[0] = make_float2(y[1].x, y[2].y);
+    if (y[0].x == 123.456f) dst_lo[0] = to_out<FMT>(y[1]);
 #else
     fft32<true>(y, [&](int i) {
-        dst_lo[32 * i] = make_float2(y[i].x, y[i].y);
-        if (i + 16 < kRowsLast) dst_lo[32 * (i + 16)] = make_float2(y[i + 16].x, y[i + 16].y);
-        else if (i + 16 < kFftValid / 32) dst_hi[32 * (i + 16)] = make_float2(y[i + 16].x, y[i + 16].y);
+        dst_lo[32 * i] = to_out<FMT>(y[i]);
+        if (i + 16 < kRowsLast) dst_lo[32 * (i + 16)] = to_out<FMT>(y[i + 16]);
+        else if (i + 16 < kFftValid / 32) dst_hi[32 * (i + 16)] = to_out<FMT>(y[i + 16]);
     });
 #endif
 }
@@ -272,10 +299,13 @@ __device__ __forceinline__ void pass4_store(v2f (&y)[32], float2* dst_lo, float2
 // streams A and B share the oscillator registers and the LDS buffer and are interleaved phase by phase, so that the
 // LDS round trip of one stream's transpose and the drain of its IQ stores run under the other stream's butterflies
 // (LDS operations of a wave execute in program order, which is all the ordering the shared buffer needs).
+template <int FMT>
 __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __restrict__ sym, size_t sym_stride,
-                                                             float2* __restrict__ iq, size_t iq_stride,
-                                                             const float2* __restrict__ osc_tab, float2* __restrict__ trash,
+                                                             typename OutSample<FMT>::type* __restrict__ iq, size_t iq_stride,
+                                                             const float2* __restrict__ osc_tab,
+                                                             typename OutSample<FMT>::type* __restrict__ trash,
                                                              int channels, int fields, int ch_per_group, int ch_groups) {
+    typedef typename OutSample<FMT>::type out_t;
     __shared__ float4 s_tw[512];
     __shared__ float4 s_h[512];
     __shared__ __align__(16) float2 s_x[kHalfWaves][32 * kRowPad];
@@ -311,8 +341,8 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     const float4* tw = s_tw + t;
     const float4* hs = s_h + t;
     const uint8_t* sym_f = sym + (size_t)f * kFieldSyms;
-    float2* iq_f = iq + (size_t)f * kFieldSyms + base + t;
-    float2* trash_t = trash + t;
+    out_t* iq_f = iq + (size_t)f * kFieldSyms + base + t;
+    out_t* trash_t = trash + t;
     const bool full_block = b != kFftBlocks - 1;
 
     // stream B of the last pair repeats stream A when the group has an odd number of channels; its rows go to trash
@@ -351,15 +381,15 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         // ---- inverse pass 2 and the stores
         const bool b_real = c + 1 < c_hi;
 #if ATSC_ABLATE & 16
-        float2* da = trash_t;
-        float2* db = trash_t;
+        out_t* da = trash_t;
+        out_t* db = trash_t;
         (void)b_real;
 #else
-        float2* da = iq_f + (size_t)c * iq_stride;
-        float2* db = b_real ? iq_f + (size_t)(c + 1) * iq_stride : trash_t;
+        out_t* da = iq_f + (size_t)c * iq_stride;
+        out_t* db = b_real ? iq_f + (size_t)(c + 1) * iq_stride : trash_t;
 #endif
-        pass4_store(xa, da, full_block ? da : trash_t);
-        pass4_store(xb, db, full_block ? db : trash_t);
+        pass4_store<FMT>(xa, da, full_block ? da : trash_t);
+        pass4_store<FMT>(xb, db, full_block ? db : trash_t);
     }
 }
 
@@ -412,8 +442,16 @@ void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, floa
                        fields);
 }
 
-void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
-                        float2* osc_tab, int channels, int fields) {
+template <int FMT>
+static void launch_fmt(hipStream_t s, unsigned grid, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
+                       const float2* osc_tab, float2* trash, int channels, int fields, int ch_per_group, int ch_groups) {
+    typedef typename OutSample<FMT>::type out_t;
+    hipLaunchKernelGGL(k_mix_fir_fft<FMT>, dim3(grid), dim3(kFftThreads), 0, s, d_sym, sym_stride, static_cast<out_t*>(d_iq),
+                       iq_stride, osc_tab, reinterpret_cast<out_t*>(trash), channels, fields, ch_per_group, ch_groups);
+}
+
+void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
+                        float2* osc_tab, int channels, int fields, int iq_format) {
     // Channels per task: as many as possible (the oscillator slice of a task is read once and shared by its channels),
     // but at least ~8 rounds of tasks over the 4096 half-wave slots of the chip so that the flat task list balances.
     static const int cpg_env = [] { const char* e = getenv("ATSC_FIR_CH_PER_TASK"); return e ? atoi(e) : 0; }();
@@ -431,8 +469,11 @@ void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, 
     const long tasks = (long)kFftBlocks * ch_groups * fields;
     const unsigned grid = (unsigned)((tasks + kHalfWaves - 1) / kHalfWaves);
     float2* trash = osc_tab + (size_t)fields * kPaddedSyms;  // kOscTabSlack complex behind the table
-    hipLaunchKernelGGL(k_mix_fir_fft, dim3(grid), dim3(kFftThreads), 0, s, d_sym, sym_stride, d_iq, iq_stride, osc_tab, trash,
-                       channels, fields, ch_per_group, ch_groups);
+    switch (iq_format) {
+        case kIqCs16: launch_fmt<kIqCs16>(s, grid, d_sym, sym_stride, d_iq, iq_stride, osc_tab, trash, channels, fields, ch_per_group, ch_groups); break;
+        case kIqCs8: launch_fmt<kIqCs8>(s, grid, d_sym, sym_stride, d_iq, iq_stride, osc_tab, trash, channels, fields, ch_per_group, ch_groups); break;
+        default: launch_fmt<kIqCf32>(s, grid, d_sym, sym_stride, d_iq, iq_stride, osc_tab, trash, channels, fields, ch_per_group, ch_groups); break;
+    }
 }
 
 }  // namespace atsc_k

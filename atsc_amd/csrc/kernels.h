@@ -25,6 +25,7 @@ constexpr int kTaps = 112;
 constexpr int kFftN = 1024;
 constexpr int kFftValid = 896;
 constexpr int kFftBlocks = (kFieldSyms + kFftValid - 1) / kFftValid;  // 291
+constexpr int kIqCf32 = 0, kIqCs16 = 1, kIqCs8 = 2;   // == ATSC_HIP_IQ_* (atsc_hip.h)
 constexpr int kOscTabSlack = 1024;  // complex64 entries behind the oscillator table that absorb stores of rows that do not exist
 
 struct DeviceTables {
@@ -68,8 +69,9 @@ void launch_osc_advance(hipStream_t s, const float2* osc_in, float2* osc_out, fl
 // launch_osc_table fills osc_tab[f] = T_(f0+f) for the batch from the state osc_in and leaves the state after the
 // batch in osc_out (offset.h:35-41); launch_mix_fir_fft then produces the IQ of every (channel, field).
 void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields);
-void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, float2* d_iq, size_t iq_stride,
-                        float2* osc_tab, int channels, int fields);
+// iq_format: kIqCf32 (complex64, the reference's payload) / kIqCs16 / kIqCs8 (SDR sink formats); iq_stride in samples.
+void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
+                        float2* osc_tab, int channels, int fields, int iq_format);
 hipError_t upload_fft_tables(const float* taps112);
 
 }  // namespace atsc_k

@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
     ap.add_argument("--fields", type=int, default=64, help="fields per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--iq-format", choices=("cf32", "cs16", "cs8"), default="cf32",
+                    help="IQ sample format of the device sink; cf32 is the reference's payload and the headline "
+                         "configuration, cs16/cs8 are the SDR sink formats (SURVEY 8f-3)")
     args = ap.parse_args()
 
     import torch
@@ -101,6 +104,10 @@ def main():
 
     C_, F = args.channels, args.fields
     enc = atsc_amd.Encoder(channels=C_, max_fields=F, device=local_rank, timing=True)
+    fmt = {"cf32": atsc_amd.IQ_CF32, "cs16": atsc_amd.IQ_CS16, "cs8": atsc_amd.IQ_CS8}[args.iq_format]
+    sample_bytes = {"cf32": 8, "cs16": 4, "cs8": 2}[args.iq_format]
+    enc.set_iq_format(fmt)
+    fir_bytes_per_sym = 1.0 + sample_bytes          # 9.0 for the reference's complex64 payload
     # synthetic 19.39 Mbps TS per channel: PRBS payload behind a 0x47 sync byte, seeded per global channel
     g = torch.Generator(device="cuda")
     g.manual_seed(1234 + rank)
@@ -109,7 +116,7 @@ def main():
     ts[:, ::5, 1:] = 0xFF          # every 5th packet null-like payload (the 'mix' flavour of config 2)
     ts = ts.contiguous()
     sym = torch.empty(C_ * F * atsc_amd.FIELD_SYMBOLS, dtype=torch.uint8, device="cuda")
-    iq = torch.empty(C_ * F * atsc_amd.FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+    iq = torch.empty(C_ * F * atsc_amd.FIELD_SYMBOLS * sample_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -146,7 +153,7 @@ def main():
     total_sym = sym_per_step_gpu * args.steps * world
     msym_s = total_sym / elapsed / 1e6
     fir_s = stage_ms["mix_fir"] / 1e3
-    fir_gbs = FIR_BYTES_PER_SYM * sym_per_step_gpu / fir_s / 1e9
+    fir_gbs = fir_bytes_per_sym * sym_per_step_gpu / fir_s / 1e9
 
     # the other stages against the same roof, with SURVEY 8(d)'s algorithmic bytes per field
     alg_bytes_field = {"rand_rs": 58656 + 64584, "interleave": 2 * 64584, "trellis_map": 64584 + 260416}
@@ -160,7 +167,7 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-        if tj.get("workload") == f"{C_} channels x {F} fields":
+        if tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8:
             traffic = tj["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -179,7 +186,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{C_} channels x {F} fields per GPU per step (BASELINE config 4 per-GPU shard), "
-                               "TS resident in HBM, symbols + complex64 IQ to a device-resident sink",
+                               f"TS resident in HBM, symbols + {'complex64' if sample_bytes == 8 else args.iq_format} IQ "
+                               "to a device-resident sink",
                    "channels_per_gpu": C_, "fields_per_step": F, "parallelism": f"channel-sharded x{world}, no collective"},
         "realtime_channels": round(msym_s / SYMBOL_RATE_MSPS, 1),
         "realtime_channels_per_gpu": round(msym_s / SYMBOL_RATE_MSPS / world, 1),
@@ -192,12 +200,12 @@ def main():
             "unit": "GB/s",
             "frac": round(fir_gbs / HBM_PEAK_GBS, 4),
             "traffic": traffic,
-            "algorithmic_bytes_per_launch": FIR_BYTES_PER_SYM * sym_per_step_gpu,
+            "algorithmic_bytes_per_launch": fir_bytes_per_sym * sym_per_step_gpu,
             "avg_launch_ms": round(stage_ms["mix_fir"], 4),
-            "note": "algorithmic bytes = 9 B/symbol (1 B symbol in + 8 B complex64 out, SURVEY 8d); the measured "
+            "note": f"algorithmic bytes = {fir_bytes_per_sym:g} B/symbol (1 B symbol in + {sample_bytes} B {args.iq_format} out, SURVEY 8d); the measured "
                     "streaming-store ceiling of this part is ~5.7 TB/s (scripts/ubench/write_bw.hip), i.e. frac <= ~0.8; "
                     "PMC traffic per launch: profiles/",
-            "whole_chain_gbs": round(CHAIN_BYTES_PER_SYM * msym_s * 1e6 / world / 1e9, 1),
+            "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes) * msym_s * 1e6 / world / 1e9, 1),
         },
         "roofline_other_stages": stages_roofline,
     }

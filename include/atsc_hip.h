@@ -89,8 +89,9 @@ int atsc_hip_process(atsc_hip_encoder* enc, const uint8_t* h_pkts, unsigned coun
  *   d_ts  : [channels][fields][312][188] u8 TS packets
  *   d_sym : [channels][fields][260416]  u8 level indices 0..7 (symbol tap after field_sync,
  *           atsc.cpp:84), or NULL to use the library's internal symbol buffer
- *   d_iq  : [channels][fields][260416]  complex64 (re,im fp32) baseband (atsc.cpp:86,89), or NULL
- *           to stop after the symbols (the oscillator still advances `fields` fields)
+ *   d_iq  : [channels][fields][260416]  complex64 (re,im fp32) baseband (atsc.cpp:86,89) -- or the handle's fixed-point
+ *           sample format, atsc_hip_set_iq_format -- or NULL to stop after the symbols (the oscillator still
+ *           advances `fields` fields)
  * Asynchronous on `stream`; 1 <= fields <= max_fields. */
 int atsc_hip_encode_batch(atsc_hip_encoder* enc, const uint8_t* d_ts, int fields, uint8_t* d_sym, void* d_iq,
                           void* stream);
@@ -108,6 +109,26 @@ int atsc_hip_encode_batch(atsc_hip_encoder* enc, const uint8_t* d_ts, int fields
  * encode_batch == begin(NULL) + finish(NULL).  Everything stays asynchronous on `stream`. */
 int atsc_hip_encode_begin(atsc_hip_encoder* enc, const uint8_t* d_ts, int fields, void* d_span_parity, void* stream);
 int atsc_hip_encode_finish(atsc_hip_encoder* enc, const void* d_carry_xor, uint8_t* d_sym, void* d_iq, void* stream);
+
+/* SDR sink adapter.  The reference hands the radio CF32 only (util/atsc_encoder.cpp:75,
+ * SOAPY_SDR_CF32); most SDR wire formats are fixed point, and 8 B/sample is what bounds the host link.  The sample
+ * format of every d_iq / h_iq / callback buffer of a handle can therefore be switched; the conversion is fused into
+ * the FIR kernel's store (no extra pass over the IQ):
+ *   CF32: interleaved re,im fp32 (8 B/sample) -- the reference's payload, default
+ *   CS16: interleaved re,im int16 (4 B/sample), q = rint(clamp(y,-1,1) * 32767), ties to even (SOAPY_SDR_CS16 scaling)
+ *   CS8 : interleaved re,im int8  (2 B/sample), q = rint(clamp(y,-1,1) * 127),   ties to even (SOAPY_SDR_CS8)
+ * y is the CF32 value of the same encode (full scale 1.0, observed peak 0.77).  No reference counterpart for the fixed-
+ * point formats: parity is pinned THROUGH the CF32 output (q must equal the formula applied to it). */
+enum { ATSC_HIP_IQ_CF32 = 0, ATSC_HIP_IQ_CS16 = 1, ATSC_HIP_IQ_CS8 = 2 };
+int atsc_hip_set_iq_format(atsc_hip_encoder* enc, int format);
+size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown format */
+
+/* atsc_hip_process with the radio-side chunking of the reference's transmitter loop (util/atsc_encoder.cpp:84-100:
+ * `transfer = min(remaining, MTU)` per writeStream call, chunks never span a field): cb(user, samples, n, format)
+ * for every piece of at most mtu_samples samples of every completed field, synchronously and in order. */
+typedef void (*atsc_hip_chunk_cb)(void* user, const void* samples, size_t nsamples, int format);
+int atsc_hip_process_chunked(atsc_hip_encoder* enc, const uint8_t* h_pkts, unsigned count, size_t mtu_samples,
+                             atsc_hip_chunk_cb cb, void* user);
 
 /* Same, from/to host memory (pageable or pinned); synchronous.  h_sym / h_iq may be NULL. */
 int atsc_hip_encode_batch_host(atsc_hip_encoder* enc, const uint8_t* h_ts, int fields, uint8_t* h_sym, void* h_iq);

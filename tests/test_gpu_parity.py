@@ -341,3 +341,86 @@ def test_config5_time_split_equals_continuous(torch_cuda):
         carry = carry ^ pars[r]
     assert np.array_equal(np.concatenate(syms), sym_c)
     assert np.array_equal(np.concatenate(iqs).view(np.uint32), iq_c.view(np.uint32))
+
+
+# ---- SDR sink adapter: fixed-point sample formats fused into the FIR store, radio-MTU chunking
+
+def _quantize(iq_f32, full):
+    """The documented formula (include/atsc_hip.h): rint(clamp(y,-1,1) * full), ties to even, exact product."""
+    return np.rint(np.clip(iq_f32.astype(np.float64), -1.0, 1.0) * full)
+
+
+@pytest.mark.parametrize("fmt,dt,full", [(atsc_amd.IQ_CS16, np.int16, 32767.0), (atsc_amd.IQ_CS8, np.int8, 127.0)])
+def test_sdr_sample_formats(torch_cuda, fmt, dt, full):
+    """CS16 / CS8 device output == the formula applied to the CF32 output of the same encode, bit for bit; and within
+    one LSB (+ the 1e-5 float tolerance) of the oracle's IQ.  3 channels so that a full pair and an odd pair (dummy
+    stream into the trash rows) are covered; 2 fields so that the short last FFT block of a field is followed by data."""
+    torch = torch_cuda
+    C_, nf = 3, 2
+    per = [ts_mix(300 + c, nf) for c in range(C_)]
+    ts = np.concatenate(per)
+    _, iq = run_device(torch, atsc_amd.Encoder(channels=C_, max_fields=nf), ts, C_, nf)
+    enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    enc.set_iq_format(fmt)
+    n = C_ * nf * FIELD_SYMBOLS
+    d_ts = torch.from_numpy(ts).cuda()
+    guard = 4096
+    d_q = torch.full((2 * n * np.dtype(dt).itemsize + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+    enc.encode_batch(d_ts.data_ptr(), nf, None, d_q.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    raw = d_q.cpu().numpy()
+    assert (raw[-guard:] == 0x5A).all(), "store past the end of the fixed-point buffer"
+    q = raw[:-guard].view(dt).astype(np.float64)
+    want = _quantize(iq.view(np.float32), full)
+    bad = np.flatnonzero(q != want)
+    assert bad.size == 0, f"{bad.size} samples differ from the formula, first {bad[:4]}: {q[bad[:4]]} vs {want[bad[:4]]}"
+    for c in range(C_):
+        ref = Oracle().process_fields(per[c], nf, want=("iq",))["iq"]
+        got = q.reshape(C_, -1)[c]
+        assert np.abs(got - ref.astype(np.float64) * full).max() <= 0.5 + IQ_TOL * full + 1e-9
+
+
+def test_sdr_format_saturates(torch_cuda):
+    """Symbols outside the 8VSB alphabet (level index 255 -> 504.25) drive the FIR far beyond full scale: the fixed-point
+    formats clamp to +-32767 / +-127 instead of wrapping."""
+    torch = torch_cuda
+    sym = torch.full((FIELD_SYMBOLS,), 255, dtype=torch.uint8, device="cuda")
+    f32 = torch.empty(FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    atsc_amd.Encoder(channels=1, max_fields=1).mix_fir(sym.data_ptr(), 1, f32.data_ptr(), st)
+    torch.cuda.synchronize()
+    y = f32.cpu().numpy().view(np.float32)
+    assert np.abs(y).max() > 2.0
+    for fmt, dt, full in ((atsc_amd.IQ_CS16, np.int16, 32767.0), (atsc_amd.IQ_CS8, np.int8, 127.0)):
+        enc = atsc_amd.Encoder(channels=1, max_fields=1)
+        enc.set_iq_format(fmt)
+        q = torch.empty(2 * FIELD_SYMBOLS * np.dtype(dt).itemsize, dtype=torch.uint8, device="cuda")
+        enc.mix_fir(sym.data_ptr(), 1, q.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.array_equal(q.cpu().numpy().view(dt).astype(np.float64), _quantize(y, full))
+
+
+def test_process_chunked_radio_mtu(torch_cuda):
+    """atsc_hip_process_chunked: the transmitter loop of util/atsc_encoder.cpp:84-100 -- pieces of min(remaining, MTU)
+    samples, never spanning a field -- in CS16; concatenated pieces == the batch output."""
+    nf, mtu = 3, 65536
+    ts = ts_mt(11, nf)
+    enc = atsc_amd.Encoder(channels=1, max_fields=2)
+    enc.set_iq_format(atsc_amd.IQ_CS16)
+    sizes, parts = [], []
+
+    def on_chunk(ptr, nsamp, fmt):
+        assert fmt == atsc_amd.IQ_CS16
+        sizes.append(nsamp)
+        parts.append(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int16)), shape=(2 * nsamp,)).copy())
+
+    enc.process_chunked(ts, nf * 312, mtu, on_chunk)
+    per_field = [mtu] * (FIELD_SYMBOLS // mtu) + [FIELD_SYMBOLS % mtu]
+    assert sizes == per_field * nf
+    ref = atsc_amd.Encoder(channels=1, max_fields=nf)
+    _, iq = run_device(torch_cuda, ref, ts, 1, nf)
+    assert np.array_equal(np.concatenate(parts).astype(np.float64), _quantize(iq.view(np.float32), 32767.0))
+    with pytest.raises(atsc_amd.AtscHipError):
+        enc.process_chunked(ts, 1, 0, on_chunk)
+    with pytest.raises(atsc_amd.AtscHipError):
+        enc.set_iq_format(7)
