@@ -37,7 +37,10 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
            "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes",
            "atsc_hip_process_chunked",
-           "atsc_hip_error_string", "atsc_hip_version")
+           "atsc_hip_error_string", "atsc_hip_version",
+           # include/atsc_ts_ingest.h
+           "atsc_ts_ingest_create", "atsc_ts_ingest_destroy", "atsc_ts_ingest_push", "atsc_ts_ingest_available",
+           "atsc_ts_ingest_pop", "atsc_ts_ingest_pop_padded", "atsc_ts_ingest_get_stats", "atsc_ts_null_packet")
 
 
 class AtscHipError(RuntimeError):
@@ -52,6 +55,12 @@ class StreamState(C.Structure):
     _fields_ = [("field_index", C.c_uint64), ("coded_tail", C.c_uint8 * INTERLEAVER_TAIL),
                 ("last_group", C.c_uint8 * 12), ("z2", C.c_uint8 * 12), ("z0_next", C.c_uint8 * 12),
                 ("z0_prev", C.c_uint8 * 12)]
+
+
+class IngestStats(C.Structure):
+    _fields_ = [("bytes_in", C.c_uint64), ("bytes_dropped", C.c_uint64), ("packets_out", C.c_uint64),
+                ("nulls_stuffed", C.c_uint64), ("sync_errors", C.c_uint64), ("sync_losses", C.c_uint64),
+                ("locked", C.c_int)]
 
 
 FIELD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint)
@@ -103,6 +112,19 @@ def load_library():
     L.atsc_hip_error_string.argtypes = [C.c_int]
     L.atsc_hip_error_string.restype = C.c_char_p
     L.atsc_hip_version.restype = C.c_char_p
+    L.atsc_ts_ingest_create.argtypes = [C.c_int, C.c_int]
+    L.atsc_ts_ingest_create.restype = vp
+    L.atsc_ts_ingest_destroy.argtypes = [vp]
+    L.atsc_ts_ingest_destroy.restype = None
+    for f in (L.atsc_ts_ingest_push, L.atsc_ts_ingest_pop, L.atsc_ts_ingest_pop_padded):
+        f.argtypes = [vp, u8p, C.c_size_t]
+        f.restype = C.c_size_t
+    L.atsc_ts_ingest_available.argtypes = [vp]
+    L.atsc_ts_ingest_available.restype = C.c_size_t
+    L.atsc_ts_ingest_get_stats.argtypes = [vp, C.POINTER(IngestStats)]
+    L.atsc_ts_ingest_get_stats.restype = None
+    L.atsc_ts_null_packet.argtypes = [u8p]
+    L.atsc_ts_null_packet.restype = None
     _lib = L
     return L
 
@@ -227,3 +249,45 @@ def get_table(which, handle=None):
     out = np.zeros(n, dt)
     check(load_library().atsc_hip_get_table(handle, which, out.ctypes.data, out.nbytes))
     return out
+
+
+class TsIngest:
+    """ctypes view of include/atsc_ts_ingest.h: sync acquisition / resync / null stuffing in front of the encoder."""
+
+    def __init__(self, lock_packets=0, loss_packets=0):
+        self.L = load_library()
+        self.h = self.L.atsc_ts_ingest_create(lock_packets, loss_packets)
+        if not self.h:
+            raise AtscHipError("atsc_ts_ingest_create: invalid argument")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.atsc_ts_ingest_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def push(self, data):
+        import numpy as np
+        buf = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+        return self.L.atsc_ts_ingest_push(self.h, buf.ctypes.data, buf.size)
+
+    def available(self):
+        return self.L.atsc_ts_ingest_available(self.h)
+
+    def pop(self, max_packets):
+        import numpy as np
+        out = np.empty(max_packets * TS_PACKET_BYTES, np.uint8)
+        n = self.L.atsc_ts_ingest_pop(self.h, out.ctypes.data, max_packets)
+        return out[:n * TS_PACKET_BYTES]
+
+    def pop_padded(self, packets):
+        import numpy as np
+        out = np.empty(packets * TS_PACKET_BYTES, np.uint8)
+        stuffed = self.L.atsc_ts_ingest_pop_padded(self.h, out.ctypes.data, packets)
+        return out, stuffed
+
+    def stats(self):
+        st = IngestStats()
+        self.L.atsc_ts_ingest_get_stats(self.h, C.byref(st))
+        return {k: getattr(st, k) for k, _ in IngestStats._fields_}

@@ -24,6 +24,14 @@ public:
     // N 188-byte TS packets in; fn(iq, 260416*8) once per completed 312-packet field, synchronously, in order.
     virtual void process(uint8_t* pkt, unsigned count, std::function<void(void*, unsigned)> fn) = 0;
 
+    // SDR sink adapter (reference caller: util/atsc_encoder.cpp:75,84-100).  The sample format of the
+    // buffers handed to fn: cf32 (the reference's), cs16 or cs8 (converted inside the FIR kernel); and the transmitter
+    // loop's chunking: write(samples, n) for every piece of at most mtu samples of every completed field.
+    enum class iq_format { cf32 = ATSC_HIP_IQ_CF32, cs16 = ATSC_HIP_IQ_CS16, cs8 = ATSC_HIP_IQ_CS8 };
+    virtual void set_iq_format(iq_format f) = 0;
+    virtual void process_chunked(uint8_t* pkt, unsigned count, size_t mtu_samples,
+                                 std::function<void(const void*, size_t)> write) = 0;
+
     // device: HIP ordinal; max_fields: how many complete fields one process() call may push through the GPU
     // in a single batch (1 reproduces the reference's field-at-a-time latency; larger amortises launches).
     static std::unique_ptr<atsc_encoder> create(int device = 0, int max_fields = 8);
@@ -48,6 +56,21 @@ public:
     void process(uint8_t* pkt, unsigned count, std::function<void(void*, unsigned)> fn) override {
         const int rc = atsc_hip_process(h_, pkt, count, &hip_encoder::trampoline, &fn);
         if (rc != ATSC_HIP_OK) throw std::runtime_error(std::string("atsc_hip_process: ") + atsc_hip_error_string(rc));
+    }
+
+    void set_iq_format(iq_format f) override {
+        const int rc = atsc_hip_set_iq_format(h_, static_cast<int>(f));
+        if (rc != ATSC_HIP_OK) throw std::runtime_error(std::string("atsc_hip_set_iq_format: ") + atsc_hip_error_string(rc));
+    }
+    void process_chunked(uint8_t* pkt, unsigned count, size_t mtu_samples,
+                         std::function<void(const void*, size_t)> write) override {
+        const int rc = atsc_hip_process_chunked(
+            h_, pkt, count, mtu_samples,
+            [](void* user, const void* samples, size_t n, int) {
+                (*static_cast<std::function<void(const void*, size_t)>*>(user))(samples, n);
+            },
+            &write);
+        if (rc != ATSC_HIP_OK) throw std::runtime_error(std::string("atsc_hip_process_chunked: ") + atsc_hip_error_string(rc));
     }
 
 private:

@@ -15,9 +15,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "atsc_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(atsc_hip_[a-z_0-9]+)\s*\(", txt)))
+    """Every function declared in include/*.h (typedef'd callback types excluded)."""
+    syms = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        txt = re.sub(r"typedef[^;{]*\([^;]*;", "", txt)
+        syms |= set(re.findall(r"\b(atsc_(?:hip|ts)_[a-z_0-9]+)\s*\(", txt))
+    return sorted(syms)
 
 
 def test_library_exports_every_declared_symbol():
@@ -25,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     syms = header_symbols()
     assert len(syms) >= 15
     for s in syms:
-        assert hasattr(lib, s), f"{s} declared in include/atsc_hip.h but not exported"
+        assert hasattr(lib, s), f"{s} declared in include/*.h but not exported"
     assert sorted(atsc_amd.EXPORTS) == syms, "python binding list and header disagree"
 
 

@@ -424,3 +424,23 @@ def test_process_chunked_radio_mtu(torch_cuda):
         enc.process_chunked(ts, 1, 0, on_chunk)
     with pytest.raises(atsc_amd.AtscHipError):
         enc.set_iq_format(7)
+
+
+def test_null_driver_with_ingest(torch_cuda, tmp_path):
+    """The null-sink driver (counterpart of util/atsc_encoder_null.cpp) end to end: junk ahead of the stream is
+    skipped by the ingest front-end, whole fields are encoded, the trailing half field is dropped like the reference
+    does -- or completed with null packets with `pad`; CS16 halves the bytes handed to the sink."""
+    import json
+    import os
+    import subprocess
+    exe = os.path.join(atsc_amd.ROOT, "atsc_amd", "bin", "atsc_encoder_null")
+    assert os.path.exists(exe), "driver not built (atsc_amd/csrc/Makefile)"
+    ts = ts_mt(8, 4)[:int(3.5 * 312) * 188]
+    path = tmp_path / "in.ts"
+    path.write_bytes(bytes([1, 2, 3] * 100) + ts.tobytes())
+    for extra, fields, per_field, stuffed in (([], 3, FIELD_SYMBOLS * 8, 0), (["0", "cs16", "pad"], 4, FIELD_SYMBOLS * 4, 156)):
+        out = subprocess.run([exe, str(path), "2"] + extra, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        r = json.loads(out.stdout)
+        assert r["fields"] == fields and r["iq_bytes"] == fields * per_field
+        assert r["bytes_dropped"] == 300 and r["nulls_stuffed"] == stuffed and r["sync_losses"] == 0
