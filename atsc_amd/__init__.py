@@ -38,6 +38,9 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
            "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes",
            "atsc_hip_process_chunked",
            "atsc_hip_error_string", "atsc_hip_version",
+           # include/atsc_hip_resample.h
+           "atsc_hip_resampler_design", "atsc_hip_resampler_create", "atsc_hip_resampler_destroy",
+           "atsc_hip_resampler_out_count", "atsc_hip_resample", "atsc_hip_resampler_reset",
            # include/atsc_ts_ingest.h
            "atsc_ts_ingest_create", "atsc_ts_ingest_destroy", "atsc_ts_ingest_push", "atsc_ts_ingest_available",
            "atsc_ts_ingest_pop", "atsc_ts_ingest_pop_padded", "atsc_ts_ingest_get_stats", "atsc_ts_null_packet")
@@ -112,6 +115,14 @@ def load_library():
     L.atsc_hip_error_string.argtypes = [C.c_int]
     L.atsc_hip_error_string.restype = C.c_char_p
     L.atsc_hip_version.restype = C.c_char_p
+    L.atsc_hip_resampler_design.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, vp]
+    L.atsc_hip_resampler_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(vp)]
+    L.atsc_hip_resampler_destroy.argtypes = [vp]
+    L.atsc_hip_resampler_destroy.restype = None
+    L.atsc_hip_resampler_out_count.argtypes = [vp, C.c_size_t]
+    L.atsc_hip_resampler_out_count.restype = C.c_size_t
+    L.atsc_hip_resample.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, vp]
+    L.atsc_hip_resampler_reset.argtypes = [vp]
     L.atsc_ts_ingest_create.argtypes = [C.c_int, C.c_int]
     L.atsc_ts_ingest_create.restype = vp
     L.atsc_ts_ingest_destroy.argtypes = [vp]
@@ -291,3 +302,38 @@ class TsIngest:
         st = IngestStats()
         self.L.atsc_ts_ingest_get_stats(self.h, C.byref(st))
         return {k: getattr(st, k) for k, _ in IngestStats._fields_}
+
+
+def resampler_design(L, M, K=16, beta=0.0):
+    """Prototype taps h[0..K*L) as the library designs them (host only)."""
+    import numpy as np
+    h = np.zeros(K * L, np.float32)
+    check(load_library().atsc_hip_resampler_design(L, M, K, beta, h.ctypes.data))
+    return h
+
+
+class Resampler:
+    """ctypes view of include/atsc_hip_resample.h (SDR-rate polyphase resampler, L/M times the symbol rate)."""
+
+    def __init__(self, channels, L, M, K=16, beta=0.0, out_format=IQ_CF32, device=0):
+        self.L_ = load_library()
+        self.channels, self.L, self.M, self.K, self.fmt = channels, L, M, K, out_format
+        h = C.c_void_p()
+        check(self.L_.atsc_hip_resampler_create(device, channels, L, M, K, beta, out_format, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L_.atsc_hip_resampler_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def out_count(self, n_in):
+        return self.L_.atsc_hip_resampler_out_count(self.h, n_in)
+
+    def resample(self, d_in, n_in, in_stride, d_out, out_stride, stream=None):
+        check(self.L_.atsc_hip_resample(self.h, d_in, n_in, in_stride, d_out, out_stride, stream))
+
+    def reset(self):
+        check(self.L_.atsc_hip_resampler_reset(self.h))

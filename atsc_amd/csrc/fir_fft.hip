@@ -26,6 +26,7 @@
 // reference's exact fp32 recursion (offset.h:35-41), so a task (block, field, channel group) needs no
 // history and the grid is a flat list of equal tasks.
 #include "kernels.h"
+#include "iq_format.h"
 #ifndef ATSC_ABLATE
 #define ATSC_ABLATE 0
 #endif
@@ -248,31 +249,6 @@ __device__ __forceinline__ void pass2_spectrum(v2f (&x)[32], const float4* hs) {
 #pragma unroll
     for (int p = 0; p < 32; ++p) x[p] = y[p];
 }
-// ---- output sample formats (SDR sink adapter; the reference only ever hands out CF32,
-// util/atsc_encoder.cpp:75).  CS16 / CS8 are the SoapySDR-style fixed-point formats, full scale 1.0 <-> 32767 / 127:
-//   q = rint(clamp(y, -1, 1) * 32767)   (round half to even of the exact product; one v_cvt_pknorm_i16_f32)
-//   q = rint(clamp(y, -1, 1) * 127)     (fma onto 1.5*2^23: the integer lands in the low mantissa bits)
-template <int FMT> struct OutSample;
-template <> struct OutSample<kIqCf32> { typedef float2 type; };
-template <> struct OutSample<kIqCs16> { typedef uint32_t type; };
-template <> struct OutSample<kIqCs8>  { typedef uint16_t type; };
-
-template <int FMT>
-__device__ __forceinline__ typename OutSample<FMT>::type to_out(v2f y) {
-    if constexpr (FMT == kIqCf32) {
-        return make_float2(y.x, y.y);
-    } else if constexpr (FMT == kIqCs16) {
-        uint32_t r;
-        asm("v_cvt_pknorm_i16_f32 %0, %1, %2" : "=v"(r) : "v"(y.x), "v"(y.y));
-        return r;
-    } else {
-        const float re = __builtin_amdgcn_fmed3f(y.x, -1.0f, 1.0f), im = __builtin_amdgcn_fmed3f(y.y, -1.0f, 1.0f);
-        const v2f m = vfma((v2f){re, im}, (v2f){127.0f, 127.0f}, (v2f){12582912.0f, 12582912.0f});
-        // bytes: low byte of re's bits, low byte of im's bits
-        return (uint16_t)__builtin_amdgcn_perm(__float_as_uint(m.y), __float_as_uint(m.x), 0x0c0c0400u);
-    }
-}
-
 // inverse pass 2 (over kA) -> y[t + 32*nA]; rows nA < 28 are free of circular wrap.  Rows leave as soon as the last
 // butterfly stage has produced them.  dst_lo serves rows 0..17, dst_hi rows 18..27 (a trash area for the last block
 // of a field, which has only 18 rows): always 28 stores, so every vmcnt wait in the loop is exact.
