@@ -85,6 +85,11 @@ def main():
                          "configuration, cs16/cs8 are the SDR sink formats (SURVEY 8f-3)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner, ...) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import atsc_amd
 
@@ -97,7 +102,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the 8VSB path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torchrun the RCCL path runs even with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -215,7 +220,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the checker must never take the bench down
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

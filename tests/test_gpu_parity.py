@@ -444,3 +444,19 @@ def test_null_driver_with_ingest(torch_cuda, tmp_path):
         r = json.loads(out.stdout)
         assert r["fields"] == fields and r["iq_bytes"] == fields * per_field
         assert r["bytes_dropped"] == 300 and r["nulls_stuffed"] == stuffed and r["sync_losses"] == 0
+
+
+def test_edge_sizes(torch_cuda):
+    """Ragged / extreme shapes: an empty process() call, one field, more than 64 fields in one batch (the carry scan
+    walks fields in passes of 64), a field count that is not a multiple of anything."""
+    enc = atsc_amd.Encoder(channels=1, max_fields=1)
+    enc.process(np.zeros(0, np.uint8), 0, lambda *a: pytest.fail("no field was completed"))
+    ts1 = ts_mix(1, 1)
+    sym, iq = run_device(torch_cuda, enc, ts1, 1, 1)
+    want = Oracle().process_fields(ts1, 1, want=("sym", "iq"))
+    assert np.array_equal(sym, want["sym"]) and np.abs(iq.view(np.float32) - want["iq"]).max() <= IQ_TOL
+    nf = 131
+    ts = ts_mt(131, nf)
+    big = atsc_amd.Encoder(channels=1, max_fields=nf)
+    sym, _ = run_device(torch_cuda, big, ts, 1, nf, want_iq=False)
+    assert np.array_equal(sym, Oracle().symbols(ts, nf))
