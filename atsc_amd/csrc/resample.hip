@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -67,6 +68,83 @@ __global__ __launch_bounds__(kResThreads) void k_resample(const float2* __restri
     }
 }
 
+
+// ---- integer upsampling fast path (M == 1, L in {2,3,4}, K == 16: the "2x the symbol rate" SDR case).
+// The generic kernel reads K taps + K samples from LDS per output (192 B at K = 16) and is LDS-bandwidth-bound.
+// Here a thread owns R = 16/L consecutive input positions and all L phases of each: its K+R-1 samples live in
+// registers as a sliding window (one LDS read per new sample), the L*K taps are wave-uniform (scalar loads), and
+// the 16 outputs of a thread leave through a padded LDS image so that the global stores are coalesced:
+// ~28 B of LDS traffic per output instead of 192.  Phase 0 of the Nyquist prototype is the identity (centre tap
+// 1.0, all others exactly 0: atsc_hip_resampler_design), so it is copied, not computed.
+template <int L>
+struct UpGeom {
+    static constexpr int R = 16 / L;                 // input positions per thread
+    static constexpr int kIn = kResThreads * R;      // input positions per block
+    static constexpr int kOut = kIn * L;             // outputs per block
+};
+
+template <int L, int K, int FMT>
+__global__ __launch_bounds__(kResThreads) void k_upsample(const float2* __restrict__ in, size_t n_in, size_t in_stride,
+                                                          const float2* __restrict__ hist,
+                                                          typename OutSample<FMT>::type* __restrict__ out,
+                                                          size_t out_stride, const float* __restrict__ hp) {
+    typedef UpGeom<L> G;
+    constexpr int R = G::R;
+    constexpr int kWin = G::kIn + K - 1;
+    // sample w of the window sits at w + w / R (one pad per R: a thread's first read is 8*(R+1) bytes from its neighbour's)
+    __shared__ float2 s_x[kWin + kWin / R + 1];
+    __shared__ float2 s_y[G::kOut + G::kOut / 16 + 1];   // output o at o + o / 16
+    const int tid = threadIdx.x;
+    const int ch = blockIdx.y;
+    const long i0 = (long)blockIdx.x * G::kIn;           // first input position of the block
+    const float2* in_c = in + (size_t)ch * in_stride;
+    const float2* hist_c = hist + (size_t)ch * (K - 1);
+    for (int w = tid; w < kWin; w += kResThreads) {
+        const long i = i0 - (K - 1) + w;
+        float2 v;
+        if (i >= 0) v = i < (long)n_in ? in_c[i] : make_float2(0.f, 0.f);
+        else v = hist_c[i + (K - 1)];
+        s_x[w + w / R] = v;
+    }
+    __syncthreads();
+    // window of this thread: samples i0 + tid*R - (K-1) ... i0 + tid*R + R-1  = window slots tid*R ... tid*R + K+R-2
+    v2f_t x[K + R - 1];
+#pragma unroll
+    for (int w = 0; w < K + R - 1; ++w) {
+        const int ws = tid * R + w;
+        const float2 v = s_x[ws + ws / R];
+        x[w] = (v2f_t){v.x, v.y};
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int o = (tid * R + r) * L;
+        // phase 0: y[L*i] = x[i - K/2]
+        {
+            const v2f_t y = x[r + K - 1 - K / 2];
+            s_y[o + o / 16] = make_float2(y.x, y.y);
+        }
+#pragma unroll
+        for (int ph = 1; ph < L; ++ph) {
+            v2f_t acc = {0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float c = hp[ph * K + k];          // uniform: scalar load
+                acc = __builtin_elementwise_fma(x[r + K - 1 - k], (v2f_t){c, c}, acc);
+            }
+            s_y[o + ph + (o + ph) / 16] = make_float2(acc.x, acc.y);
+        }
+    }
+    __syncthreads();
+    const size_t j0 = (size_t)i0 * L;
+    const size_t n_out = n_in * L;
+    typename OutSample<FMT>::type* out_c = out + (size_t)ch * out_stride + j0;
+    const int n_here = (int)min((size_t)G::kOut, n_out - j0);
+    for (int o = tid; o < n_here; o += kResThreads) {
+        const float2 v = s_y[o + o / 16];
+        out_c[o] = to_out<FMT>((v2f_t){v.x, v.y});
+    }
+}
+
 // new history = last K-1 samples of [old history | this call's input]
 __global__ void k_resample_history(const float2* __restrict__ in, size_t n_in, size_t in_stride, const float2* __restrict__ hist,
                                    float2* __restrict__ hist_new, int K) {
@@ -99,6 +177,7 @@ struct atsc_hip_resampler {
     float* d_hp = nullptr;        // [L][K] polyphase taps
     float2* d_hist[2] = {nullptr, nullptr};
     int cur = 0;
+    bool nyquist = false;        // phase 0 is the identity with delay K/2 (integer-upsampling fast path)
 };
 
 static bool args_ok(int L, int M, int K) {
@@ -150,6 +229,8 @@ extern "C" int atsc_hip_resampler_create(int device, int channels, int L, int M,
     atsc_hip_resampler_design(L, M, K, beta, h.data());
     for (int ph = 0; ph < L; ++ph)
         for (int k = 0; k < K; ++k) hp[(size_t)ph * K + k] = h[(size_t)k * L + ph];
+    r->nyquist = true;
+    for (int k = 0; k < K; ++k) r->nyquist = r->nyquist && hp[k] == (k == K / 2 ? 1.0f : 0.0f);
     const size_t hist_bytes = sizeof(float2) * (size_t)channels * (K - 1);
     if ((e = hipMalloc(&r->d_hp, sizeof(float) * hp.size())) != hipSuccess ||
         (e = hipMalloc(&r->d_hist[0], hist_bytes)) != hipSuccess || (e = hipMalloc(&r->d_hist[1], hist_bytes)) != hipSuccess ||
@@ -188,6 +269,28 @@ static void launch_resample(atsc_hip_resampler* r, hipStream_t s, const float2* 
                        static_cast<out_t*>(out), n_out, out_stride, r->d_hp, r->L, r->M, r->K, r->q0);
 }
 
+template <int L, int FMT>
+static void launch_upsample(atsc_hip_resampler* r, hipStream_t s, const float2* in, size_t n_in, size_t in_stride, void* out,
+                            size_t out_stride) {
+    typedef typename OutSample<FMT>::type out_t;
+    const dim3 grid((unsigned)((n_in + UpGeom<L>::kIn - 1) / UpGeom<L>::kIn), (unsigned)r->channels);
+    hipLaunchKernelGGL((k_upsample<L, 16, FMT>), grid, dim3(kResThreads), 0, s, in, n_in, in_stride, r->d_hist[r->cur],
+                       static_cast<out_t*>(out), out_stride, r->d_hp);
+}
+
+template <int FMT>
+static bool try_upsample(atsc_hip_resampler* r, hipStream_t s, const float2* in, size_t n_in, size_t in_stride, void* out,
+                         size_t out_stride) {
+    static const bool off = getenv("ATSC_RESAMPLE_GENERIC") != nullptr;   // A/B switch for the tests
+    if (off || r->M != 1 || r->K != 16 || !r->nyquist || r->q0 != 0) return false;
+    switch (r->L) {
+        case 2: launch_upsample<2, FMT>(r, s, in, n_in, in_stride, out, out_stride); return true;
+        case 3: launch_upsample<3, FMT>(r, s, in, n_in, in_stride, out, out_stride); return true;
+        case 4: launch_upsample<4, FMT>(r, s, in, n_in, in_stride, out, out_stride); return true;
+        default: return false;
+    }
+}
+
 extern "C" int atsc_hip_resample(atsc_hip_resampler* r, const void* d_in, size_t n_in, size_t in_stride, void* d_out,
                                  size_t out_stride, void* stream) {
     if (!r || !d_in || !d_out || n_in < 1 || in_stride < n_in) return ATSC_HIP_ERR_ARG;
@@ -201,9 +304,18 @@ extern "C" int atsc_hip_resample(atsc_hip_resampler* r, const void* d_in, size_t
     auto* in = static_cast<const float2*>(d_in);
     if (n_out) {
         switch (r->fmt) {
-            case ATSC_HIP_IQ_CS16: launch_resample<kIqCs16>(r, s, in, n_in, in_stride, d_out, n_out, out_stride); break;
-            case ATSC_HIP_IQ_CS8: launch_resample<kIqCs8>(r, s, in, n_in, in_stride, d_out, n_out, out_stride); break;
-            default: launch_resample<kIqCf32>(r, s, in, n_in, in_stride, d_out, n_out, out_stride); break;
+            case ATSC_HIP_IQ_CS16:
+                if (!try_upsample<kIqCs16>(r, s, in, n_in, in_stride, d_out, out_stride))
+                    launch_resample<kIqCs16>(r, s, in, n_in, in_stride, d_out, n_out, out_stride);
+                break;
+            case ATSC_HIP_IQ_CS8:
+                if (!try_upsample<kIqCs8>(r, s, in, n_in, in_stride, d_out, out_stride))
+                    launch_resample<kIqCs8>(r, s, in, n_in, in_stride, d_out, n_out, out_stride);
+                break;
+            default:
+                if (!try_upsample<kIqCf32>(r, s, in, n_in, in_stride, d_out, out_stride))
+                    launch_resample<kIqCf32>(r, s, in, n_in, in_stride, d_out, n_out, out_stride);
+                break;
         }
     }
     hipLaunchKernelGGL(k_resample_history, dim3(r->channels), dim3(64), 0, s, in, n_in, in_stride, r->d_hist[r->cur],

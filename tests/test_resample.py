@@ -94,7 +94,7 @@ def _run(torch, rs, x, n_in_list):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("L,M,K", [(1, 1, 2), (2, 1, 16), (8, 7, 16), (3, 5, 16), (125, 108, 12)])
+@pytest.mark.parametrize("L,M,K", [(1, 1, 2), (2, 1, 16), (3, 1, 16), (4, 1, 16), (2, 1, 12), (8, 7, 16), (3, 5, 16), (125, 108, 12)])
 def test_gpu_matches_float64_model(L, M, K):
     import torch
     rng = np.random.default_rng(L * 100 + M)
@@ -112,7 +112,9 @@ def test_gpu_matches_float64_model(L, M, K):
 
 @pytest.mark.gpu
 def test_gpu_phase0_passthrough_and_chunking():
-    """Integer L: y[L*i] == x[i - K/2] bit for bit; any chunking of the input gives bit-identical output."""
+    """Integer L: y[L*i] == x[i - K/2] bit for bit; any chunking of the input gives bit-identical output.  (L = 2..4 with
+    K = 16 run the sliding-window kernel k_upsample, everything else the generic k_resample: L = 2, K = 12 below is the
+    generic kernel on the same data, and both are held to the same float64 model in test_gpu_matches_float64_model.)"""
     import torch
     rng = np.random.default_rng(1)
     ch, n, L, K = 2, 70_001, 2, 16
