@@ -370,17 +370,19 @@ static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned cou
     if (e->cfg.channels != 1) return ATSC_HIP_ERR_STATE;
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t F = e->cfg.max_fields;
-    if (!e->d_ts) {
-        // sized for CF32, the largest sample format
-        HIP_TRY(hipMalloc(&e->d_ts, F * kFieldTs));
-        HIP_TRY(hipMalloc(&e->d_iq, F * kFieldSyms * sizeof(float2)));
-        HIP_TRY(hipHostMalloc(&e->h_ts_pinned, F * kFieldTs, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(&e->h_iq_pinned, F * kFieldSyms * sizeof(float2), hipHostMallocDefault));
-    }
+    // streaming buffers, sized for CF32 (the largest sample format); each is retried if an earlier call ran out of memory
+    if (!e->d_ts) HIP_TRY(hipMalloc(&e->d_ts, F * kFieldTs));
+    if (!e->d_iq) HIP_TRY(hipMalloc(&e->d_iq, F * kFieldSyms * sizeof(float2)));
+    if (!e->h_ts_pinned) HIP_TRY(hipHostMalloc(&e->h_ts_pinned, F * kFieldTs, hipHostMallocDefault));
+    if (!e->h_iq_pinned) HIP_TRY(hipHostMalloc(&e->h_iq_pinned, F * kFieldSyms * sizeof(float2), hipHostMallocDefault));
     const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
     const size_t field_bytes = (size_t)kFieldSyms * ss;
-    // copy-before-return contract (atsc.cpp:66)
-    e->pending.insert(e->pending.end(), h_pkts, h_pkts + (size_t)count * ATSC_HIP_TS_PACKET_BYTES);
+    // copy-before-return contract (atsc.cpp:66); no exception may cross the C boundary
+    try {
+        e->pending.insert(e->pending.end(), h_pkts, h_pkts + (size_t)count * ATSC_HIP_TS_PACKET_BYTES);
+    } catch (const std::bad_alloc&) {
+        return static_cast<int>(hipErrorOutOfMemory);
+    }
     size_t done = 0;
     while (e->pending.size() - done >= (size_t)kFieldTs) {
         const int nf = (int)std::min<size_t>((e->pending.size() - done) / kFieldTs, F);

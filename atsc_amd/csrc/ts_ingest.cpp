@@ -127,9 +127,13 @@ extern "C" size_t atsc_ts_ingest_available(const atsc_ts_ingest* h) {
 extern "C" size_t atsc_ts_ingest_push(atsc_ts_ingest* h, const uint8_t* data, size_t n) {
     if (!h) return 0;
     if (data && n) {
-        h->raw.insert(h->raw.end(), data, data + n);
         h->st.bytes_in += n;
-        h->run();
+        try {   // no exception may cross the C boundary: on out-of-memory the chunk is dropped and counted as such
+            h->raw.insert(h->raw.end(), data, data + n);
+            h->run();
+        } catch (const std::bad_alloc&) {
+            h->st.bytes_dropped += n;
+        }
     }
     return atsc_ts_ingest_available(h);
 }
