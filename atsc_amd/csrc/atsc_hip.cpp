@@ -42,6 +42,7 @@ struct atsc_hip_encoder {
     int pending_fields = 0;    // fields of a batch between encode_begin and encode_finish
     int last_fields = 0;       // field count of the last batch (internal symbol buffer is packed with it)
     int iq_format = ATSC_HIP_IQ_CF32;
+    int fir_form = ATSC_HIP_FIR_AUTO;
     void* d_tables = nullptr;
 
     // streaming path (1 channel)
@@ -135,6 +136,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     e->dtab.fsync = tb + off_fs;
     e->dtab.prbs = tb + off_pr;
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
+    TRY_OR_FREE(upload_mfma_tables(e->tab.taps));
 
     // per-channel working buffers
     e->buf.max_fields = cfg->max_fields;
@@ -238,9 +240,24 @@ int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, vo
     const float2* oin = e->d_osc[e->osc_cur];
     float2* oout = e->d_osc[e->osc_cur ^ 1];
     if (d_iq) {
-        launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields);
+        // Two forms of the mixer + FIR (atsc_hip_set_fir_form): overlap-save FFT on the vector units, or -- the
+        // oscillator being shared by all channels of the handle -- a banded GEMM on the matrix cores.  With complex64
+        // output both run into the same HBM read+write ceiling; the matrix-core form has the lower compute
+        // floor and wins once the output shrinks (CS16 / CS8), provided the 32-channel tile is reasonably full.
+        static const int form_env = [] {
+            const char* v = getenv("ATSC_FIR_FORM");   // A/B runs: overrides the handle's setting
+            return !v ? 0 : (!strcmp(v, "fft") ? ATSC_HIP_FIR_FFT : (!strcmp(v, "mfma") ? ATSC_HIP_FIR_MFMA : 0));
+        }();
+        const int form = form_env ? form_env : e->fir_form;
+        const bool mfma = form == ATSC_HIP_FIR_MFMA ||
+                          (form == ATSC_HIP_FIR_AUTO && C >= kMfmaMinChannels && e->iq_format != ATSC_HIP_IQ_CF32);
+        launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields, mfma);
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
-        launch_mix_fir_fft(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms, e->d_osc_tab, C, fields, e->iq_format);
+        if (mfma)
+            launch_mix_fir_mfma(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms,
+                                reinterpret_cast<const float*>(e->d_osc_tab), C, fields, e->iq_format);
+        else
+            launch_mix_fir_fft(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms, e->d_osc_tab, C, fields, e->iq_format);
     } else {
         launch_osc_advance(s, oin, oout, e->scale, (unsigned)fields);
     }
@@ -353,6 +370,13 @@ extern "C" size_t atsc_hip_iq_sample_bytes(int format) {
         case ATSC_HIP_IQ_CS8: return 2;
         default: return 0;
     }
+}
+
+extern "C" int atsc_hip_set_fir_form(atsc_hip_encoder* e, int form) {
+    if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_MFMA) return ATSC_HIP_ERR_ARG;
+    if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    e->fir_form = form;
+    return ATSC_HIP_OK;
 }
 
 extern "C" int atsc_hip_set_iq_format(atsc_hip_encoder* e, int format) {

@@ -369,14 +369,21 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     }
 }
 
-// Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41)
+// Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41).
+// planes != 0: the same memory as [f][re plane | im plane] of floats (the layout k_mix_fir_mfma reads).
 __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in, float2* __restrict__ tab,
-                                                   float2* __restrict__ out, float2 sc, int fields) {
+                                                   float2* __restrict__ out, float2 sc, int fields, int planes) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kPaddedSyms) return;
     float2 t = in[i];
+    float* pl = reinterpret_cast<float*>(tab);
     for (int f = 0; f < fields; ++f) {
-        tab[(size_t)f * kPaddedSyms + i] = t;
+        if (planes) {
+            pl[((size_t)f * 2) * kPaddedSyms + i] = t.x;
+            pl[((size_t)f * 2 + 1) * kPaddedSyms + i] = t.y;
+        } else {
+            tab[(size_t)f * kPaddedSyms + i] = t;
+        }
         const float t2 = __fmul_rn(t.y, sc.y);
         const float t3 = __fmul_rn(t.x, sc.y);
         t = make_float2(__fmaf_rn(t.x, sc.x, -t2), __fmaf_rn(t.y, sc.x, t3));
@@ -413,9 +420,10 @@ hipError_t upload_fft_tables(const float* taps112) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_fft_tab), h.data(), sizeof(float) * h.size());
 }
 
-void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields) {
+void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields,
+                      bool planes) {
     hipLaunchKernelGGL(k_osc_table, dim3((kPaddedSyms + 255) / 256), dim3(256), 0, s, osc_in, osc_tab, osc_out, scale,
-                       fields);
+                       fields, planes ? 1 : 0);
 }
 
 template <int FMT>

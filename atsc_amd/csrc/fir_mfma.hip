@@ -1,0 +1,332 @@
+// gfx950 mixer + RRC FIR for MANY channels as a banded GEMM on the matrix cores.
+//
+//   y[c][i] = sum_{k<111} taps[k] * T_f[i+k] * x_c[i+k]          (reference: offset.h:11-45, filter.h:9-69)
+//
+// All channels of a handle share the oscillator T_f (offset.h:9: one table per encoder, advanced once per field), so
+// for a tile of 16 consecutive outputs i0..i0+15 the products W[p][m] = taps[m-p] * T_f[i0+m] (m < 126) are the same for
+// every channel and
+//
+//   Y[2p+comp][c] = sum_m W_comp[p][m] * X[m][c],        X[m][c] = level(symbol of channel c at i0+m)
+//
+// is a GEMM: M = 32 rows (16 outputs x re/im), N = channels, K = 128.  The levels 2v - 5.75 are EXACT in fp16, and a
+// weight splits into two fp16 pieces hi + lo (scaled by 2^16 so that both stay in fp16's range) that carry 21+ bits of
+// it, so the products are exact and the fp32 accumulation of v_mfma_f32_32x32x16_f16 gives the same accuracy class as
+// the fp32 paths (measured max error vs the reference: see DESIGN.md) at 16x the fp32 vector rate.
+//
+// One wave = one (field, run of tiles, group of 32*NT channels) task:
+//   * A operand (weights) is generated in registers, straight in the MFMA lane layout (lane = row 2p+comp, 8 consecutive
+//     m): 8 taps from LDS (four copies of the tap array shifted by 0..3 so that every lane's window is 16-byte aligned),
+//     8 oscillator values from a wave-private LDS window (the 256 re and 256 im values that 8 consecutive tiles need,
+//     refilled from the batch table's re / im planes once per 8 tiles, the next refill prefetched in registers),
+//     multiply, split -- shared by the NT channel tiles of the wave.
+//   * B operand (levels) is a sliding window of 8 K-steps in registers: a tile advances by 16 outputs = exactly one
+//     K-step, so each tile converts only 8 new symbols per lane (bytes -> fp16 by an exponent trick, exact for every
+//     byte value) and the rest of the window is a renaming of registers (the tile loop is unrolled by 8).  The symbol
+//     bytes come from a wave-private LDS window that is refilled once per 8 tiles with whole 128-byte pieces of every
+//     channel's row (coalesced 16-byte loads, each symbol line fetched once): per-tile 8-byte loads would touch 32
+//     lines per instruction, and with the IQ write stream flushing the L2 those lines were re-fetched from HBM for
+//     every tile (measured: the kernel ran at 0.4 of its own no-store speed).
+//   * C (32x32 fp32) has re/im of two consecutive outputs in four consecutive registers of a lane: 16 bytes of the IQ
+//     stream.  It leaves through a wave-private LDS image [channel][16 outputs] so that every global store instruction
+//     writes whole 128-byte lines (8 channels x one line), in the handle's sample format.
+// No workgroup barriers after the tap table is staged; waves are independent (LDS operations of a wave execute in
+// program order).
+#include "iq_format.h"
+#include "kernels.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace atsc_k {
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = 16;                          // outputs per tile = one MFMA K-step
+constexpr int kTilesPerField = kFieldSyms / kTile; // 16276
+constexpr int kKSteps = 8;                         // 128 >= 16 + 110 inputs feed a tile
+constexpr int kTapCopy = 176;                      // floats per shifted copy of the padded tap array
+constexpr int kTapLead = 16;                       // zeros ahead of tap 0 (p <= 15)
+constexpr float kWScale = 65536.0f;                // weights are scaled into fp16's normal range; exact to undo
+constexpr int kStageRow = 36;                      // floats per channel row of the output image (32 + 4: conflict-free b128)
+constexpr int kMfmaWaves = 4;
+constexpr int kSymRow = 136;                       // bytes per channel row of the symbol window (128 + 8: conflict-free b64 reads)
+
+static_assert(kFieldSyms % kTile == 0, "tiles must cover a field exactly");
+static_assert(kTile * (kKSteps - 1) + kTile >= kTile + 110, "K must cover the filter");
+
+__device__ float g_taps_mfma[4 * kTapCopy];
+
+__device__ __forceinline__ void lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 8 level indices (bytes) -> 8 fp16 levels 2v - 5.75 (signal.h:13-18).  0x6400 | v is the fp16 number 1024 + v.
+__device__ __forceinline__ h8 levels8(uint2 w) {
+    const h2 k1024 = {(_Float16)1024.0f, (_Float16)1024.0f}, k2 = {(_Float16)2.0f, (_Float16)2.0f},
+             kp = {(_Float16)-5.75f, (_Float16)-5.75f};
+    h2 r[4];
+    const uint32_t src[2] = {w.x, w.y};
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const uint32_t t0 = __builtin_amdgcn_perm(0u, src[d], 0x0c010c00u) | 0x64006400u;
+        const uint32_t t1 = __builtin_amdgcn_perm(0u, src[d], 0x0c030c02u) | 0x64006400u;
+        r[2 * d] = (__builtin_bit_cast(h2, t0) - k1024) * k2 + kp;
+        r[2 * d + 1] = (__builtin_bit_cast(h2, t1) - k1024) * k2 + kp;
+    }
+    return (h8){r[0].x, r[0].y, r[1].x, r[1].y, r[2].x, r[2].y, r[3].x, r[3].y};
+}
+
+template <int FMT> struct Out2;   // two consecutive samples of a channel, one store
+template <> struct Out2<kIqCf32> { typedef float4 type; };
+template <> struct Out2<kIqCs16> { typedef uint2 type; };
+template <> struct Out2<kIqCs8>  { typedef uint32_t type; };
+
+template <int FMT>
+__device__ __forceinline__ typename Out2<FMT>::type pack2(float4 v) {
+    if constexpr (FMT == kIqCf32) {
+        return v;
+    } else if constexpr (FMT == kIqCs16) {
+        return make_uint2(to_out<kIqCs16>((v2f_t){v.x, v.y}), to_out<kIqCs16>((v2f_t){v.z, v.w}));
+    } else {
+        return (uint32_t)to_out<kIqCs8>((v2f_t){v.x, v.y}) | ((uint32_t)to_out<kIqCs8>((v2f_t){v.z, v.w}) << 16);
+    }
+}
+
+}  // namespace
+
+template <int FMT, int NT>
+__global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_mfma(const uint8_t* __restrict__ sym, size_t sym_stride,
+                                                                     typename OutSample<FMT>::type* __restrict__ iq,
+                                                                     size_t iq_stride, const float* __restrict__ planes,
+                                                                     typename OutSample<FMT>::type* __restrict__ trash,
+                                                                     int channels, int fields, int run8, int runs_per_field,
+                                                                     int ch_groups) {
+    typedef typename OutSample<FMT>::type out_t;
+    typedef typename Out2<FMT>::type out2_t;
+    __shared__ __align__(16) float s_taps[4 * kTapCopy];
+    __shared__ __align__(16) float s_stage[kMfmaWaves][32 * kStageRow];
+    __shared__ __align__(16) uint8_t s_sym[kMfmaWaves][32 * NT * kSymRow];   // 128 symbols x 32*NT channels, rows padded to 136 B
+    __shared__ __align__(16) float s_osc[kMfmaWaves][2][2][256];   // double buffer x [re | im] of positions i_group .. +255
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4 * kTapCopy; i += 64 * kMfmaWaves) s_taps[i] = g_taps_mfma[i];
+    __syncthreads();
+
+    const int lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // task = (channel group, run, field); neighbouring waves take neighbouring runs of one field (shared oscillator lines)
+    const long task = (long)blockIdx.x * kMfmaWaves + wv;
+    const int run = (int)(task % runs_per_field);
+    const long g = task / runs_per_field;
+    const int cg = (int)(g % ch_groups);
+    const int f = (int)(g / ch_groups);
+    if (f >= fields) return;
+    const int tile0 = run * run8 * 8;
+
+    // A role: row r = 2p + comp
+    const int p = r >> 1, comp = r & 1;
+    const int sh = (4 - (p & 3)) & 3;                               // which shifted tap copy is 16-byte aligned for this lane
+    const float* tapp = s_taps + sh * kTapCopy + (kTapLead + 8 * h - p - sh);   // + 16*ks, + j
+    const float* ow0 = s_osc[wv][0][comp] + 8 * h;                              // + 512*(group&1) + 16*u + 16*ks, + j
+    // refill of the oscillator window: lane l brings floats 4l..4l+3 of the re plane and of the im plane
+    const float* pre_src = planes + (size_t)f * 2 * kPaddedSyms + 4 * lane;
+    float* pre_dst = s_osc[wv][0][0] + 4 * lane;                                // + 512*(group&1); re at +0, im at +256
+    auto osc_fetch = [&](int tile_first, float4& a, float4& b) {
+        // a group that starts past the field is never used: keep its address inside the table (a valid group reads at
+        // most up to position 16 * 16272 + 255, inside the padded table)
+        const int i = (tile_first < kTilesPerField ? tile_first : 0) * kTile;
+        a = *reinterpret_cast<const float4*>(pre_src + i);
+        b = *reinterpret_cast<const float4*>(pre_src + kPaddedSyms + i);
+    };
+    float* stage = s_stage[wv];
+    float* st_w = stage + r * kStageRow + 4 * h;                    // + 8*g: outputs 4g+2h, 4g+2h+1 of channel r
+    const float* st_r = stage + (lane >> 3) * kStageRow + 4 * (lane & 7);   // + 8*q rows: channel 8q + lane/8, outputs 2(lane&7)..+1
+
+    h8 bw[kKSteps][NT];
+    // Symbol window of a group of 8 tiles starting at tile T: positions [16T + 128, 16T + 256) of every channel, i.e. the
+    // newest K-step of tiles T+1 .. T+8.  Tile T itself takes the last 16 bytes of the previous window (kept in registers).
+    uint8_t* symw = s_sym[wv];
+    const uint8_t* sym_rd = symw + r * kSymRow + 8 * h;                         // + 32*nt rows, + 16*(u-1)
+    uint8_t* sym_wr = symw + (lane >> 3) * kSymRow + 16 * (lane & 7);           // + 8*q rows
+#define ATSC_Q8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+    // lane's 16-byte piece of channel 8q + lane/8 (channels past the end read the last channel; never stored)
+#define ATSC_SYM_SRC1(q)                                                                                                 \
+    const uint8_t* sym_src##q = sym + (size_t)min(cg * 32 * NT + 8 * q + (lane >> 3), channels - 1) * sym_stride +       \
+                                (size_t)f * kFieldSyms + 16 * (lane & 7);
+    ATSC_Q8(ATSC_SYM_SRC1)
+    // The prefetch registers are named scalars handled by macros on purpose: as arrays indexed in (unrolled) loops they
+    // are left in scratch memory by the compiler (a 144-byte private segment, 2 GB of scratch traffic per launch).
+#define ATSC_SYM_LOAD1(q) if constexpr (q < 4 * NT) ps##q = *reinterpret_cast<const uint4*>(sym_src##q + src_);
+#define ATSC_SYM_FETCH(tile_first)                                                                                      \
+    do {                                                                                                                \
+        const int tf_ = (tile_first);                                                                                   \
+        const int pos_ = (tf_ < kTilesPerField ? tf_ : 0) * kTile + 128 + 16 * (lane & 7);                              \
+        const int src_ = (pos_ < kFieldSyms ? pos_ : pos_ - kFieldSyms) - 16 * (lane & 7); /* sync-head copy past the end */ \
+        ATSC_Q8(ATSC_SYM_LOAD1)                                                                                         \
+    } while (0)
+#define ATSC_SYM_PARK1(q) if constexpr (q < 4 * NT) *reinterpret_cast<uint4*>(sym_wr + 8 * q * kSymRow) = ps##q;
+#define ATSC_SYM_PARK() do { ATSC_Q8(ATSC_SYM_PARK1) } while (0)
+    uint4 ps0, ps1, ps2, ps3, ps4, ps5, ps6, ps7;
+    uint2 tl0, tl1;
+    ps0 = ps1 = ps2 = ps3 = ps4 = ps5 = ps6 = ps7 = make_uint4(0, 0, 0, 0);
+    tl0 = tl1 = make_uint2(0, 0);
+    // level window of the run's first tile: the 128 symbols ahead of it, through the same coalesced path
+    ATSC_SYM_FETCH(tile0 - 8);
+    ATSC_SYM_PARK();
+    lds_order();
+    // positions [16 T0, 16 T0 + 128): K-steps 0..6 of the first tile, and its newest K-step as the "tail"
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int ks = 0; ks < kKSteps - 1; ++ks)
+            bw[ks][nt] = levels8(*reinterpret_cast<const uint2*>(sym_rd + 32 * nt * kSymRow + 16 * ks));
+        (nt == 0 ? tl0 : tl1) = *reinterpret_cast<const uint2*>(sym_rd + 32 * nt * kSymRow + 112);
+    }
+    lds_order();
+    ATSC_SYM_FETCH(tile0);
+    ATSC_SYM_PARK();
+    float4 pre_re, pre_im;
+    osc_fetch(tile0, pre_re, pre_im);
+    *reinterpret_cast<float4*>(pre_dst) = pre_re;
+    *reinterpret_cast<float4*>(pre_dst + 256) = pre_im;
+    lds_order();
+    for (int t8 = 0; t8 < run8; ++t8) {
+        const float* ow = ow0 + 512 * (t8 & 1);
+        // next group's oscillator window: loads issued now, parked in the other LDS buffer at the group's last tile
+        osc_fetch(tile0 + 8 * (t8 + 1), pre_re, pre_im);
+        ATSC_SYM_FETCH(tile0 + 8 * (t8 + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // The last run of a field is short.  Tiles past the end are computed like any other (their loads stay inside
+            // the sync-head copy and the padded oscillator table) and stored to the trash area, as are channels past
+            // the last one: the number of loads and stores per tile is fixed, so every vmcnt wait the compiler places
+            // is an exact count and never waits for the IQ stores of the previous tile.
+            const int tile = tile0 + 8 * t8 + u;
+            const bool tile_ok = tile < kTilesPerField;
+            const int i0 = tile * kTile;
+            // newest K-step of the level window
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const uint2 w = u == 0 ? (nt == 0 ? tl0 : tl1)
+                                       : *reinterpret_cast<const uint2*>(sym_rd + 32 * nt * kSymRow + 16 * (u - 1));
+                bw[(u + kKSteps - 1) & 7][nt] = levels8(w);
+            }
+            if (u == 7) {
+                // the group's last read of the windows is behind us: keep the tail, then park the next group's windows
+                lds_order();
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    (nt == 0 ? tl0 : tl1) = *reinterpret_cast<const uint2*>(sym_rd + 32 * nt * kSymRow + 112);
+                lds_order();
+                ATSC_SYM_PARK();
+                float* d = pre_dst + 512 * ((t8 + 1) & 1);
+                *reinterpret_cast<float4*>(d) = pre_re;
+                *reinterpret_cast<float4*>(d + 256) = pre_im;
+            }
+            f16v acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+            // Software pipeline over the K-steps: the weights of step ks+1 are generated (LDS read, multiply, split)
+            // while the four MFMAs of step ks run.
+            auto weights = [&](int ks, h8& ahi, h8& alo) {
+                const float4 o0 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks);
+                const float4 o1 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(tapp + 16 * ks);
+                const float4 c1 = *reinterpret_cast<const float4*>(tapp + 16 * ks + 4);
+                const float x[8] = {c0.x * o0.x, c0.y * o0.y, c0.z * o0.z, c0.w * o0.w,
+                                    c1.x * o1.x, c1.y * o1.y, c1.z * o1.z, c1.w * o1.w};
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const h2 hh = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]));
+                    const h2 ll = __builtin_bit_cast(
+                        h2, __builtin_amdgcn_cvt_pkrtz(x[j] - (float)hh.x, x[j + 1] - (float)hh.y));
+                    ahi[j] = hh.x; ahi[j + 1] = hh.y;
+                    alo[j] = ll.x; alo[j + 1] = ll.y;
+                }
+            };
+            h8 ahi[2], alo[2];
+            weights(0, ahi[0], alo[0]);
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+                const int cur = ks & 1;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[cur], bw[(u + ks) & 7][nt], acc[nt], 0, 0, 0);
+                if (ks + 1 < kKSteps) weights(ks + 1, ahi[cur ^ 1], alo[cur ^ 1]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[cur], bw[(u + ks) & 7][nt], acc[nt], 0, 0, 0);
+            }
+            // C: register 4g+e of lane (r, h) is row 8g + 4h + e = output 4g + 2h + e/2, component e&1, of channel r
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                constexpr float inv = 1.0f / kWScale;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<float4*>(st_w + 8 * gq) =
+                        make_float4(acc[nt][4 * gq] * inv, acc[nt][4 * gq + 1] * inv, acc[nt][4 * gq + 2] * inv,
+                                    acc[nt][4 * gq + 3] * inv);
+                lds_order();
+                const int cbase = cg * 32 * NT + 32 * nt + (lane >> 3);
+                out_t* dst = iq + (size_t)f * kFieldSyms + i0 + 2 * (lane & 7);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow);
+                    const int c = cbase + 8 * q;
+                    out_t* d = (tile_ok && c < channels) ? dst + (size_t)c * iq_stride : trash + 2 * lane;
+                    *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
+                }
+                lds_order();
+            }
+        }
+        lds_order();   // the other window buffer is complete and ordered before the next group reads it
+    }
+}
+
+hipError_t upload_mfma_tables(const float* taps112) {
+    std::vector<float> pad(kTapCopy + 4, 0.f), h(4 * kTapCopy);
+    for (int k = 0; k < 111; ++k) pad[kTapLead + k] = taps112[k] * kWScale;
+    for (int s = 0; s < 4; ++s)
+        for (int i = 0; i < kTapCopy; ++i) h[s * kTapCopy + i] = pad[i + s];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_taps_mfma), h.data(), sizeof(float) * h.size());
+}
+
+template <int FMT, int NT>
+static void launch_nt(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride, const float* planes,
+                      void* trash, int channels, int fields, int run8) {
+    typedef typename OutSample<FMT>::type out_t;
+    const int runs = (kTilesPerField + 8 * run8 - 1) / (8 * run8);
+    const int ch_groups = (channels + 32 * NT - 1) / (32 * NT);
+    const long tasks = (long)runs * ch_groups * fields;
+    const unsigned grid = (unsigned)((tasks + kMfmaWaves - 1) / kMfmaWaves);
+    hipLaunchKernelGGL((k_mix_fir_mfma<FMT, NT>), dim3(grid), dim3(64 * kMfmaWaves), 0, s, d_sym, sym_stride,
+                       static_cast<out_t*>(d_iq), iq_stride, planes, static_cast<out_t*>(trash), channels, fields, run8, runs,
+                       ch_groups);
+}
+
+void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
+                         const float* osc_planes, int channels, int fields, int iq_format) {
+    static const int run8_env = [] { const char* e = getenv("ATSC_FIR_MFMA_RUN8"); return e ? atoi(e) : 0; }();
+    const int run8 = run8_env > 0 ? run8_env : 4;   // 32 tiles = 512 outputs per wave task
+    // One 32-channel tile per wave (NT = 1: 158 VGPRs, 3 waves per SIMD).  Two tiles per wave would share the weight
+    // generation but need ~320 VGPRs with the prefetch registers: measured 3.1 ms against 2.4 ms.
+    // kOscTabSlack complex64 (8 KB) behind the table: 64 lanes x 16 B of don't-care stores land there
+    void* trash = const_cast<float*>(osc_planes) + (size_t)fields * 2 * kPaddedSyms;
+#define ATSC_MFMA_CASE(F) launch_nt<F, 1>(s, d_sym, sym_stride, d_iq, iq_stride, osc_planes, trash, channels, fields, run8)
+    switch (iq_format) {
+        case kIqCs16: ATSC_MFMA_CASE(kIqCs16); break;
+        case kIqCs8: ATSC_MFMA_CASE(kIqCs8); break;
+        default: ATSC_MFMA_CASE(kIqCf32); break;
+    }
+#undef ATSC_MFMA_CASE
+}
+
+}  // namespace atsc_k

@@ -68,10 +68,17 @@ void launch_osc_advance(hipStream_t s, const float2* osc_in, float2* osc_out, fl
 // Mixer + FIR (fir_fft.hip).  osc_tab: (fields x 261248 + kOscTabSlack) complex64 scratch.
 // launch_osc_table fills osc_tab[f] = T_(f0+f) for the batch from the state osc_in and leaves the state after the
 // batch in osc_out (offset.h:35-41); launch_mix_fir_fft then produces the IQ of every (channel, field).
-void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields);
+void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields,
+                      bool planes);
 // iq_format: kIqCf32 (complex64, the reference's payload) / kIqCs16 / kIqCs8 (SDR sink formats); iq_stride in samples.
 void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
                         float2* osc_tab, int channels, int fields, int iq_format);
 hipError_t upload_fft_tables(const float* taps112);
+// Mixer + FIR on the matrix cores for handles with many channels (fir_mfma.hip): osc_planes is the osc_tab memory
+// filled by launch_osc_table(..., planes = true).
+void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
+                         const float* osc_planes, int channels, int fields, int iq_format);
+hipError_t upload_mfma_tables(const float* taps112);
+constexpr int kMfmaMinChannels = 16;   // below this the 32-wide channel tile of the MFMA form is mostly padding: FFT form
 
 }  // namespace atsc_k

@@ -123,6 +123,15 @@ enum { ATSC_HIP_IQ_CF32 = 0, ATSC_HIP_IQ_CS16 = 1, ATSC_HIP_IQ_CS8 = 2 };
 int atsc_hip_set_iq_format(atsc_hip_encoder* enc, int format);
 size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown format */
 
+/* Which kernel computes offset.process_field + filter.process_field (src/atsc/atsc.cpp:85-86).  Both are parity-checked
+ * against the same oracle to the same tolerance; their outputs agree to ~5e-7 of full scale but are not bit-identical.
+ *   FFT : overlap-save fast convolution on the vector units (any channel count)
+ *   MFMA: banded GEMM on the matrix cores; needs the oscillator shared by many channels to pay off
+ *   AUTO: MFMA for handles with >= 16 channels and a fixed-point sample format, FFT otherwise (default)
+ * No reference counterpart (the reference has one scalar/AVX form, filter.h:16-69). */
+enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2 };
+int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);
+
 /* atsc_hip_process with the radio-side chunking of the reference's transmitter loop (util/atsc_encoder.cpp:84-100:
  * `transfer = min(remaining, MTU)` per writeStream call, chunks never span a field): cb(user, samples, n, format)
  * for every piece of at most mtu_samples samples of every completed field, synchronously and in order. */

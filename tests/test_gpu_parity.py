@@ -154,8 +154,9 @@ def test_channel_groups_11_channels(torch_cuda):
 
 def test_full_size_batch_channel_independence(torch_cuda):
     """BASELINE config 4 per-GPU shard (64 channels x 64 fields) through a size-independent property: channels are
-    independent and deterministic, so 64 copies of one stream give 64 bit-identical outputs, equal to that stream
-    encoded alone, which is itself checked against the oracle on its first and last fields."""
+    independent and deterministic, so 64 copies of one stream give 64 bit-identical outputs; their symbols equal that
+    stream encoded alone, whose IQ (the few-channel FFT form of the FIR, the batch runs the matrix-core form) agrees
+    within the tolerance; and channel 0 is checked against the oracle on its first and last fields."""
     torch = torch_cuda
     C_, nf = 64, 64
     one = ts_mt(4321, nf)
@@ -174,12 +175,13 @@ def test_full_size_batch_channel_independence(torch_cuda):
     solo.encode_batch(d_one.data_ptr(), nf, s_sym.data_ptr(), s_iq.data_ptr(), st)
     torch.cuda.synchronize()
     sym2 = d_sym.view(C_, n)
-    iq2 = torch.view_as_real(d_iq).view(C_, 2 * n).view(torch.int32)
+    iqf = torch.view_as_real(d_iq).view(C_, 2 * n)
     assert bool((sym2 == s_sym.unsqueeze(0)).all()), "channels differ in symbols"
-    assert bool((iq2 == torch.view_as_real(s_iq).view(1, 2 * n).view(torch.int32)).all()), "channels differ in IQ bits"
+    assert bool((iqf.view(torch.int32) == iqf[0:1].view(torch.int32)).all()), "channels differ in IQ bits"
+    assert float((iqf[0] - torch.view_as_real(s_iq).view(2 * n)).abs().max()) <= IQ_TOL, "batch and solo forms disagree"
     want = Oracle().process_fields(one, nf, want=("sym", "iq"))
     assert np.array_equal(s_sym.cpu().numpy(), want["sym"])
-    got = torch.view_as_real(s_iq).cpu().numpy().reshape(-1)
+    got = iqf[0].cpu().numpy()
     for f in (0, nf - 1):
         sl = slice(2 * f * FIELD_SYMBOLS, 2 * (f + 1) * FIELD_SYMBOLS)
         assert np.abs(got[sl] - want["iq"][sl]).max() <= IQ_TOL
@@ -460,3 +462,67 @@ def test_edge_sizes(torch_cuda):
     big = atsc_amd.Encoder(channels=1, max_fields=nf)
     sym, _ = run_device(torch_cuda, big, ts, 1, nf, want_iq=False)
     assert np.array_equal(sym, Oracle().symbols(ts, nf))
+
+
+# ---- matrix-core form of the mixer + FIR (fir_mfma.hip): handles with >= 16 channels
+
+@pytest.mark.parametrize("C_", [16, 33, 40, 64, 70])
+def test_mfma_form_every_channel_against_oracle(torch_cuda, C_):
+    """Channel counts around the 32-channel MFMA tile (one tile, one + a sliver, two, two + a sliver) x 3 fields (first
+    field with zero history, the look-ahead into the sync-head copy at every field end): every channel's IQ against
+    the oracle, symbols bit-exact, and nothing written past the buffers."""
+    torch = torch_cuda
+    nf = 3
+    per = [ts_mix(500 + c, nf) for c in range(C_)]
+    ts = np.concatenate(per)
+    enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    enc.set_fir_form(atsc_amd.FIR_MFMA)
+    n = C_ * nf * FIELD_SYMBOLS
+    d_ts = torch.from_numpy(ts).cuda()
+    d_sym = torch.empty(n, dtype=torch.uint8, device="cuda")
+    guard = 1 << 16
+    d_iq = torch.full((2 * n + guard,), float("nan"), dtype=torch.float32, device="cuda")
+    enc.encode_batch(d_ts.data_ptr(), nf, d_sym.data_ptr(), d_iq.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    iq = d_iq.cpu().numpy()
+    assert np.isnan(iq[2 * n:]).all(), "store past the end of the IQ buffer"
+    iq = iq[:2 * n].reshape(C_, -1)
+    assert not np.isnan(iq).any(), "samples left unwritten"
+    sym = d_sym.cpu().numpy().reshape(C_, -1)
+    worst = 0.0
+    o = Oracle()
+    for c in range(C_):
+        want = Oracle().process_fields(per[c], nf, want=("sym", "iq"))
+        assert np.array_equal(sym[c], want["sym"]), f"channel {c}"
+        worst = max(worst, float(np.abs(iq[c] - want["iq"]).max()))
+    print(f"{C_} channels: IQ max abs err {worst:.3e}")
+    assert worst <= IQ_TOL
+    del o
+    # the two forms of the FIR agree far inside the tolerance (they are not bit-identical)
+    fft = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    fft.set_fir_form(atsc_amd.FIR_FFT)
+    _, iq_fft = run_device(torch, fft, ts, C_, nf)
+    assert np.abs(iq_fft.view(np.float32).reshape(C_, -1) - iq).max() <= 2e-6
+    with pytest.raises(atsc_amd.AtscHipError):
+        fft.set_fir_form(3)
+
+
+def test_mfma_form_sample_formats(torch_cuda):
+    """CS16 / CS8 out of the matrix-core form == the formula applied to its own CF32 output (33 channels)."""
+    torch = torch_cuda
+    C_, nf = 33, 1
+    ts = np.concatenate([ts_mt(900 + c, nf) for c in range(C_)])
+    ref = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    ref.set_fir_form(atsc_amd.FIR_MFMA)
+    _, iq = run_device(torch, ref, ts, C_, nf)
+    d_ts = torch.from_numpy(ts).cuda()
+    n = C_ * nf * FIELD_SYMBOLS
+    for fmt, dt, full in ((atsc_amd.IQ_CS16, np.int16, 32767.0), (atsc_amd.IQ_CS8, np.int8, 127.0)):
+        enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+        enc.set_iq_format(fmt)          # AUTO picks the matrix-core form for 33 channels with a fixed-point format
+        d_q = torch.full((2 * n * np.dtype(dt).itemsize + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
+        enc.encode_batch(d_ts.data_ptr(), nf, None, d_q.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        raw = d_q.cpu().numpy()
+        assert (raw[-4096:] == 0x5A).all()
+        assert np.array_equal(raw[:-4096].view(dt).astype(np.float64), _quantize(iq.view(np.float32), full))
