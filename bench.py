@@ -208,7 +208,8 @@ def main():
             "algorithmic_bytes_per_launch": fir_bytes_per_sym * sym_per_step_gpu,
             "avg_launch_ms": round(stage_ms["mix_fir"], 4),
             "note": f"algorithmic bytes = {fir_bytes_per_sym:g} B/symbol (1 B symbol in + {sample_bytes} B {args.iq_format} out, SURVEY 8d); the measured "
-                    "streaming-store ceiling of this part is ~5.7 TB/s (scripts/ubench/write_bw.hip), i.e. frac <= ~0.8; "
+                    "ceiling of this part for the same traffic mix without any compute (8.5 GB written beside a 1 GB read stream, "
+                    "scripts/ubench/mix_bw.hip) is 2.08 ms = 4.6 TB/s, i.e. frac <= ~0.58; "
                     "PMC traffic per launch: profiles/",
             "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes) * msym_s * 1e6 / world / 1e9, 1),
         },
