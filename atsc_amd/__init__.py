@@ -69,7 +69,7 @@ class IngestStats(C.Structure):
 FIELD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint)
 CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
-FIR_AUTO, FIR_FFT, FIR_MFMA = 0, 1, 2
+FIR_AUTO, FIR_FFT, FIR_MFMA, FIR_FUSED = 0, 1, 2, 3
 
 _lib = None
 

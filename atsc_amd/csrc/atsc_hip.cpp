@@ -234,23 +234,30 @@ int run_back(atsc_hip_encoder* e, const uint4* carry_xor, int fields, uint8_t* d
     return static_cast<int>(hipGetLastError());
 }
 
+// which form of the mixer + FIR this batch runs (include/atsc_hip.h, atsc_hip_set_fir_form)
+int resolve_fir_form(const atsc_hip_encoder* e) {
+    static const int form_env = [] {
+        const char* v = getenv("ATSC_FIR_FORM");   // A/B runs: overrides the handle's setting
+        if (!v) return 0;
+        if (!strcmp(v, "fft")) return (int)ATSC_HIP_FIR_FFT;
+        if (!strcmp(v, "mfma")) return (int)ATSC_HIP_FIR_MFMA;
+        if (!strcmp(v, "fused")) return (int)ATSC_HIP_FIR_FUSED;
+        return 0;
+    }();
+    const int form = form_env ? form_env : e->fir_form;
+    if (form != ATSC_HIP_FIR_AUTO) return form;
+    if (e->cfg.channels >= kMfmaMinChannels) return ATSC_HIP_FIR_FUSED;
+    return ATSC_HIP_FIR_FFT;
+}
+
 int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, void* d_iq, int fields, hipStream_t s) {
     const int C = e->cfg.channels;
     mark(e, s, ATSC_HIP_STAGE_OSC);
     const float2* oin = e->d_osc[e->osc_cur];
     float2* oout = e->d_osc[e->osc_cur ^ 1];
     if (d_iq) {
-        // Two forms of the mixer + FIR (atsc_hip_set_fir_form): overlap-save FFT on the vector units, or -- the
-        // oscillator being shared by all channels of the handle -- a banded GEMM on the matrix cores.  With complex64
-        // output both run into the same HBM read+write ceiling; the matrix-core form has the lower compute
-        // floor and wins once the output shrinks (CS16 / CS8), provided the 32-channel tile is reasonably full.
-        static const int form_env = [] {
-            const char* v = getenv("ATSC_FIR_FORM");   // A/B runs: overrides the handle's setting
-            return !v ? 0 : (!strcmp(v, "fft") ? ATSC_HIP_FIR_FFT : (!strcmp(v, "mfma") ? ATSC_HIP_FIR_MFMA : 0));
-        }();
-        const int form = form_env ? form_env : e->fir_form;
-        const bool mfma = form == ATSC_HIP_FIR_MFMA ||
-                          (form == ATSC_HIP_FIR_AUTO && C >= kMfmaMinChannels && e->iq_format != ATSC_HIP_IQ_CF32);
+        const int form = resolve_fir_form(e);
+        const bool mfma = form == ATSC_HIP_FIR_MFMA;   // (the fused form does not come through here)
         launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields, mfma);
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
         if (mfma)
@@ -304,10 +311,27 @@ extern "C" int atsc_hip_encode_finish(atsc_hip_encoder* e, const void* d_carry_x
     uint8_t* sym = d_sym ? d_sym : e->d_sym;
     e->last_fields = fields;
     const size_t sym_stride = (size_t)fields * kFieldSyms;
-    int rc = run_back(e, static_cast<const uint4*>(d_carry_xor), fields, sym, sym_stride, s);
-    if (rc) return rc;
-    rc = run_mix_fir(e, sym, sym_stride, d_iq, fields, s);
-    if (rc) return rc;
+    int rc;
+    if (d_iq && resolve_fir_form(e) == ATSC_HIP_FIR_FUSED) {
+        // carries, then ONE kernel for trellis / map / sync / mixer / FIR: the symbols never pass through HBM; the symbol
+        // tap is written only if the caller asked for it (d_sym)
+        mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);
+        launch_trellis_scan(s, e->buf, static_cast<const uint4*>(d_carry_xor), e->cfg.channels, fields);
+        mark(e, s, ATSC_HIP_STAGE_OSC);
+        launch_osc_table(s, e->d_osc[e->osc_cur], e->d_osc[e->osc_cur ^ 1], e->d_osc_tab, e->scale, fields, true);
+        e->osc_cur ^= 1;
+        mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
+        launch_mix_fir_fused(s, e->dtab, e->buf, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms,
+                             reinterpret_cast<const float*>(e->d_osc_tab), e->cfg.channels, fields, e->field_index,
+                             e->iq_format);
+        rc = static_cast<int>(hipGetLastError());
+        if (rc) return rc;
+    } else {
+        rc = run_back(e, static_cast<const uint4*>(d_carry_xor), fields, sym, sym_stride, s);
+        if (rc) return rc;
+        rc = run_mix_fir(e, sym, sym_stride, d_iq, fields, s);
+        if (rc) return rc;
+    }
     mark(e, s, ATSC_HIP_STAGE_STATE);
     launch_save_state(s, e->buf, e->cfg.channels, fields);
     mark(e, s, ATSC_HIP_NSTAGES);
@@ -373,7 +397,7 @@ extern "C" size_t atsc_hip_iq_sample_bytes(int format) {
 }
 
 extern "C" int atsc_hip_set_fir_form(atsc_hip_encoder* e, int form) {
-    if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_MFMA) return ATSC_HIP_ERR_ARG;
+    if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_FUSED) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
     e->fir_form = form;
     return ATSC_HIP_OK;

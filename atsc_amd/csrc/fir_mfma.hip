@@ -33,6 +33,7 @@
 // program order).
 #include "iq_format.h"
 #include "kernels.h"
+#include "trellis_bits.h"
 
 #include <cstdlib>
 #include <vector>
@@ -327,6 +328,347 @@ void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride,
         default: ATSC_MFMA_CASE(kIqCf32); break;
     }
 #undef ATSC_MFMA_CASE
+}
+
+
+// ======================================================================================= fused trellis/map + FIR
+// k_mix_fir_fused: the matrix-core FIR above with the symbol source replaced.  Instead of reading the u8 symbols that
+// k_trellis_map wrote to HBM (1 B/symbol written, 1 B/symbol read back: the read stream beside the IQ write stream is
+// what holds both FIR forms at 0.87 of the memory system's mixed ceiling), every wave regenerates the symbols of its
+// 32 channels from the interleaved bytes (0.25 B/symbol) into a wave-private LDS ring of 256 positions per channel:
+// precoder / trellis / mapper / segment sync / field sync exactly as k_trellis_map (reference: trellis.h:10-51,
+// field_sync.h:12-26), one byte-time (12 interleaved bytes = 48 consecutive data symbols) per half-wave lane and
+// step.  The trellis state entering the run's first byte-time is the part's carry from k_trellis_scan XOR the
+// parities of the byte-times of the part before it (recomputed here: <= 206 byte-times, ~6 % of a run's work).
+// The symbol tap (d_sym) is optional: with it the ring is also copied out, one 128-byte line per channel and group.
+constexpr int kRingRow = 264;                      // bytes per channel row: 256-position ring + 8 (conflict-free b64 reads)
+constexpr int kByteTimes = kFieldCoded / 12;       // 5382 byte-times per field, 207 per part
+constexpr int kFusedRun8 = 16;                     // 128 tiles = 2048 outputs per wave task
+
+// field-relative position of the first data symbol of byte-time g (uniform)
+__device__ __forceinline__ int pos_of_bytetime(int g) {
+    if (g >= kByteTimes) return kFieldSyms;
+    const int p = g / kPartGroups, tid = g - p * kPartGroups;
+    const int t = 4 * tid, sl = t / 69, q = t - 69 * sl;
+    return kSegSyms * (1 + 12 * p + sl) + 4 + 12 * q;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
+    const uint8_t* __restrict__ il, size_t il_stride, const uint4* __restrict__ cin, const uint8_t* __restrict__ last_group,
+    const uint8_t* __restrict__ fsync, unsigned parity0, uint8_t* __restrict__ sym_out, size_t sym_stride,
+    typename OutSample<FMT>::type* __restrict__ iq, size_t iq_stride, const float* __restrict__ planes,
+    typename OutSample<FMT>::type* __restrict__ trash, int channels, int fields, int runs_per_field, int ch_groups) {
+    typedef typename OutSample<FMT>::type out_t;
+    typedef typename Out2<FMT>::type out2_t;
+    __shared__ __align__(16) float s_taps[4 * kTapCopy];
+    __shared__ __align__(16) float s_stage[kMfmaWaves][32 * kStageRow];
+    __shared__ __align__(16) uint8_t s_ring[kMfmaWaves][32 * kRingRow];
+    __shared__ __align__(16) float s_osc[kMfmaWaves][2][2][256];
+    const int tid_ = threadIdx.x;
+    for (int i = tid_; i < 4 * kTapCopy; i += 64 * kMfmaWaves) s_taps[i] = g_taps_mfma[i];
+    __syncthreads();
+
+    const int lane = tid_ & 63, wv = tid_ >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long task = (long)blockIdx.x * kMfmaWaves + wv;
+    const int run = (int)(task % runs_per_field);
+    const long gidx = task / runs_per_field;
+    const int cg = (int)(gidx % ch_groups);
+    const int f = (int)(gidx / ch_groups);
+    if (f >= fields) return;
+    const int tile0 = run * kFusedRun8 * 8;
+    const int P0 = tile0 * kTile;
+
+    // ---- FIR roles (as k_mix_fir_mfma)
+    const int p = r >> 1, comp = r & 1;
+    const int sh = (4 - (p & 3)) & 3;
+    const float* tapp = s_taps + sh * kTapCopy + (kTapLead + 8 * h - p - sh);
+    const float* ow0 = s_osc[wv][0][comp] + 8 * h;
+    const float* pre_src = planes + (size_t)f * 2 * kPaddedSyms + 4 * lane;
+    float* pre_dst = s_osc[wv][0][0] + 4 * lane;
+    auto osc_fetch = [&](int tile_first, float4& a, float4& b) {
+        const int i = (tile_first < kTilesPerField ? tile_first : 0) * kTile;
+        a = *reinterpret_cast<const float4*>(pre_src + i);
+        b = *reinterpret_cast<const float4*>(pre_src + kPaddedSyms + i);
+    };
+    float* stage = s_stage[wv];
+    float* st_w = stage + r * kStageRow + 4 * h;
+    const float* st_r = stage + (lane >> 3) * kStageRow + 4 * (lane & 7);
+
+    // ---- symbol producer: lane = (channel r, half h)
+    const int ch = min(cg * 32 + r, channels - 1);          // channels past the end recompute the last one; never stored
+    const uint8_t* il_c = il + (size_t)ch * il_stride + (size_t)f * kFieldCoded;
+    uint8_t* ring = s_ring[wv] + r * kRingRow;
+    const uint4* cin_c = cin + ((size_t)ch * fields + f) * kParts;
+    const uint32_t* fs_tab = reinterpret_cast<const uint32_t*>(fsync + (((parity0 + (unsigned)f) & 1u) ? kSegSyms : 0));
+
+    // where the run starts (uniform)
+    int next_g;        // next byte-time of the field to produce
+    int fs_j;          // next field-sync byte to produce, or -1 when not inside the field-sync segment
+    int fs_base = 0;   // 0: the field's own sync segment; kFieldSyms: its copy behind the field (field_sync.h:16)
+    int prod_pos;      // every (extended) position below it is in the ring
+    int part0;
+    {
+        const int seg = P0 / kSegSyms, jj = P0 - seg * kSegSyms;
+        if (seg == 0) {
+            next_g = 0; fs_j = jj; prod_pos = P0; part0 = 0;
+        } else {
+            const int s = seg - 1, pp = s / 12, sl = s - 12 * pp;
+            const int j = jj > 4 ? jj - 4 : 0;
+            const int t0 = 69 * sl + j / 12;
+            next_g = kPartGroups * pp + (t0 >> 2);
+            fs_j = -1; part0 = pp;
+            prod_pos = P0;   // the byte-time that holds P0 is produced first; earlier symbols of it fall on dead ring slots
+        }
+    }
+    // trellis state entering next_g: the part's carry and the parities of the part's earlier byte-times
+    uint32_t cw[3];
+    {
+        const uint4 ci = cin_c[part0];
+        uint32_t acc[3] = {0, 0, 0};
+        const int g_lo = part0 * kPartGroups;
+        for (int gq = g_lo + h; gq < next_g; gq += 8) {     // four byte-times per half in flight
+            uint32_t d[4][3];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int gg = min(gq + 2 * k4, kByteTimes - 1);
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(il_c) + 3 * gg;
+                d[k4][0] = src[0]; d[k4][1] = src[1]; d[k4][2] = src[2];
+            }
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int gg = gq + 2 * k4;
+                if (gg < next_g) {
+                    const Words3 e = canonical_group(d[k4], gg);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        uint32_t z2, z0, pr;
+                        trellis_local(e.w[k], z2, z0, pr);
+                        acc[k] ^= pr;
+                    }
+                }
+            }
+        }
+        cw[0] = ci.x ^ acc[0] ^ __shfl_xor(acc[0], 32, 64);
+        cw[1] = ci.y ^ acc[1] ^ __shfl_xor(acc[1], 32, 64);
+        cw[2] = ci.z ^ acc[2] ^ __shfl_xor(acc[2], 32, 64);
+    }
+    // reserved symbols of the field-sync segment (field_sync.h:17,23), needed by the runs that touch segment 0 or its copy
+    uint32_t rsv[3] = {0, 0, 0};
+    {
+        const uint4 c0 = cin_c[0];
+        const uint32_t cinw[3] = {c0.x, c0.y, c0.z};
+        const uint32_t* lg = (f == 0) ? reinterpret_cast<const uint32_t*>(last_group + (size_t)ch * 16)
+                                      : reinterpret_cast<const uint32_t*>(il_c - 12);
+        const Words3 pe = canonical_group(lg, kByteTimes - 1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            rsv[(k + 1) % 3] = ((cinw[k] & 0x01010101u) << 2) | ((pe.w[k] & 0x01010101u) << 1) | ((cinw[k] >> 2) & 0x01010101u);
+    }
+
+    // everything below `limit` (extended position) into the ring
+    auto produce_until = [&](int limit) {
+        while (prod_pos < limit) {
+            if (fs_j >= 0) {
+                // field-sync segment: the table, its last three dwords replaced by the reserved symbols; both halves
+                // of a channel's lane pair write alternate dwords
+                const int n = min(kSegSyms - fs_j, ((limit - prod_pos) + 3) & ~3);
+                for (int d = (fs_j >> 2) + h; d < ((fs_j + n) >> 2); d += 2) {
+                    const uint32_t v = d >= 205 ? rsv[d - 205] : fs_tab[d];
+                    *reinterpret_cast<uint32_t*>(ring + ((fs_base + 4 * d) & 255)) = v;
+                }
+                fs_j += n;
+                prod_pos += n;
+                if (fs_j >= kSegSyms) {
+                    fs_j = -1;
+                    if (fs_base) prod_pos = 1 << 30;     // the copy behind the field is complete: nothing further exists
+                    else prod_pos = kSegSyms;             // data segment 1 follows (its sync comes with byte-time 0)
+                }
+                continue;
+            }
+            // two byte-times: half h takes next_g + h
+            const int g = next_g + h;
+            const bool ok = g < kByteTimes;
+            const int gg = ok ? g : kByteTimes - 1;
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(il_c) + 3 * gg;
+            const uint32_t d3[3] = {src[0], src[1], src[2]};
+            const Words3 e = canonical_group(d3, gg);
+            uint32_t z2[3], z0[3], pr[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                trellis_local(e.w[k], z2[k], z0[k], pr[k]);
+                if (!ok) pr[k] = 0;
+            }
+            const int pp = gg / kPartGroups, tq = gg - pp * kPartGroups;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t other = __shfl_xor(pr[k], 32, 64);
+                const uint32_t cwk = cw[k] ^ (h ? other : 0u);     // half 1 follows half 0's byte-time
+                cw[k] ^= pr[k] ^ other;
+                if (ok) {
+                    const uint32_t zz2 = z2[k] ^ ((cwk & 0x01010101u) * 0xAAu);
+                    const uint32_t zz0 = z0[k] ^ (((cwk >> 1) & 0x01010101u) * 0x44u) ^ (((cwk >> 2) & 0x01010101u) * 0x11u);
+                    const uint32_t hi = zz2 | (e.w[k] & 0x55555555u);
+#pragma unroll
+                    for (int tau = 0; tau < 4; ++tau) {
+                        const int shb = 6 - 2 * tau;
+                        const uint32_t v = (((hi >> shb) & 0x03030303u) << 1) | ((zz0 >> shb) & 0x01010101u);
+                        const int t = 4 * tq + tau;
+                        const int sl = t / 69, q = t - 69 * sl;
+                        const int seg = 1 + 12 * pp + sl;
+                        const int hslot = (k + 3 - sl % 3) % 3;
+                        const int pos = kSegSyms * seg + 4 + 12 * q + 4 * hslot;
+                        *reinterpret_cast<uint32_t*>(ring + (pos & 255)) = v;
+                        if (k == 0 && q == 0) *reinterpret_cast<uint32_t*>(ring + ((kSegSyms * seg) & 255)) = 0x06010106u;
+                    }
+                }
+            }
+            next_g += 2;
+            if (next_g >= kByteTimes) {
+                fs_j = 0; fs_base = kFieldSyms; prod_pos = kFieldSyms;    // behind the field: the copy of its sync head
+            } else {
+                prod_pos = pos_of_bytetime(next_g) - 4;
+            }
+        }
+    };
+
+    // symbol tap: positions [pos, pos + 128) of the ring -> d_sym, one 128-byte line per channel (8 lanes x 16 B)
+    auto tap = [&](int pos, int pieces) {
+        if (!sym_out || (lane & 7) >= pieces) return;
+        const int pp = pos + 16 * (lane & 7);
+        if (pp >= kFieldSyms) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = cg * 32 + 8 * q + (lane >> 3);
+            const uint8_t* row = s_ring[wv] + (8 * q + (lane >> 3)) * kRingRow + (pp & 255);
+            const uint2 a = *reinterpret_cast<const uint2*>(row), b = *reinterpret_cast<const uint2*>(row + 8);
+            if (c < channels)
+                *reinterpret_cast<uint4*>(sym_out + (size_t)c * sym_stride + (size_t)f * kFieldSyms + pp) =
+                    make_uint4(a.x, a.y, b.x, b.y);
+        }
+    };
+
+    // ---- prime: symbols [P0, P0 + 112) for K-steps 0..6 of the first tile
+    produce_until(P0 + 112);
+    lds_order();
+    h8 bw[kKSteps][1];
+#pragma unroll
+    for (int ks = 0; ks < kKSteps - 1; ++ks)
+        bw[ks][0] = levels8(*reinterpret_cast<const uint2*>(ring + ((P0 + 16 * ks + 8 * h) & 255)));
+    if (run == 0) tap(0, 7);         // [0, 112): the field's first symbols, which no group's tap covers
+    lds_order();
+    produce_until(P0 + 240 + 16);
+    lds_order();
+
+    float4 pre_re, pre_im;
+    osc_fetch(tile0, pre_re, pre_im);
+    *reinterpret_cast<float4*>(pre_dst) = pre_re;
+    *reinterpret_cast<float4*>(pre_dst + 256) = pre_im;
+    lds_order();
+    for (int t8 = 0; t8 < kFusedRun8; ++t8) {
+        const float* ow = ow0 + 512 * (t8 & 1);
+        const int Tg = tile0 + 8 * t8;
+        osc_fetch(Tg + 8, pre_re, pre_im);
+        if (Tg < kTilesPerField) tap(16 * Tg + 112, 8);   // [16Tg + 112, 16Tg + 240): produced, not yet overwritten
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int tile = Tg + u;
+            const bool tile_ok = tile < kTilesPerField;
+            const int i0 = tile * kTile;
+            bw[(u + kKSteps - 1) & 7][0] = levels8(*reinterpret_cast<const uint2*>(ring + ((i0 + 112 + 8 * h) & 255)));
+            if (u == 7) {
+                // tile 7 has taken its symbols: the ring may advance to what the next group needs
+                lds_order();
+                produce_until(16 * (Tg + 8) + 240 + 16);
+                float* d = pre_dst + 512 * ((t8 + 1) & 1);
+                *reinterpret_cast<float4*>(d) = pre_re;
+                *reinterpret_cast<float4*>(d + 256) = pre_im;
+            }
+            f16v acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+            auto weights = [&](int ks, h8& ahi, h8& alo) {
+                const float4 o0 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks);
+                const float4 o1 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks + 4);
+                const float4 c0 = *reinterpret_cast<const float4*>(tapp + 16 * ks);
+                const float4 c1 = *reinterpret_cast<const float4*>(tapp + 16 * ks + 4);
+                const float x[8] = {c0.x * o0.x, c0.y * o0.y, c0.z * o0.z, c0.w * o0.w,
+                                    c1.x * o1.x, c1.y * o1.y, c1.z * o1.z, c1.w * o1.w};
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const h2 hh = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]));
+                    const h2 ll = __builtin_bit_cast(
+                        h2, __builtin_amdgcn_cvt_pkrtz(x[j] - (float)hh.x, x[j + 1] - (float)hh.y));
+                    ahi[j] = hh.x; ahi[j + 1] = hh.y;
+                    alo[j] = ll.x; alo[j + 1] = ll.y;
+                }
+            };
+            h8 ahi[2], alo[2];
+            weights(0, ahi[0], alo[0]);
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+                const int cur = ks & 1;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[cur], bw[(u + ks) & 7][0], acc, 0, 0, 0);
+                if (ks + 1 < kKSteps) weights(ks + 1, ahi[cur ^ 1], alo[cur ^ 1]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[cur], bw[(u + ks) & 7][0], acc, 0, 0, 0);
+            }
+            {
+                constexpr float inv = 1.0f / kWScale;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq)
+                    *reinterpret_cast<float4*>(st_w + 8 * gq) =
+                        make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv);
+                lds_order();
+                const int cbase = cg * 32 + (lane >> 3);
+                out_t* dst = iq + (size_t)f * kFieldSyms + i0 + 2 * (lane & 7);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow);
+                    const int c = cbase + 8 * q;
+                    out_t* d = (tile_ok && c < channels) ? dst + (size_t)c * iq_stride : trash + 2 * lane;
+                    *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
+                }
+                lds_order();
+            }
+        }
+        lds_order();
+    }
+}
+
+template <int FMT>
+static void launch_fused_fmt(hipStream_t s, const uint8_t* il, size_t il_stride, const uint4* cin, const uint8_t* last_group,
+                             const uint8_t* fsync, unsigned parity0, uint8_t* d_sym, size_t sym_stride, void* d_iq,
+                             size_t iq_stride, const float* planes, void* trash, int channels, int fields) {
+    typedef typename OutSample<FMT>::type out_t;
+    const int runs = (kTilesPerField + 8 * kFusedRun8 - 1) / (8 * kFusedRun8);
+    const int ch_groups = (channels + 31) / 32;
+    const long tasks = (long)runs * ch_groups * fields;
+    const unsigned grid = (unsigned)((tasks + kMfmaWaves - 1) / kMfmaWaves);
+    hipLaunchKernelGGL((k_mix_fir_fused<FMT>), dim3(grid), dim3(64 * kMfmaWaves), 0, s, il, il_stride, cin, last_group, fsync,
+                       parity0, d_sym, sym_stride, static_cast<out_t*>(d_iq), iq_stride, planes, static_cast<out_t*>(trash),
+                       channels, fields, runs, ch_groups);
+}
+
+void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
+                          size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
+                          int iq_format) {
+    void* trash = const_cast<float*>(osc_planes) + (size_t)fields * 2 * kPaddedSyms;
+    const unsigned par0 = (unsigned)(field_base & 1);
+    switch (iq_format) {
+        case kIqCs16:
+            launch_fused_fmt<kIqCs16>(s, b.il, b.il_stride, b.cin, b.last_group, t.fsync, par0, d_sym, sym_stride, d_iq, iq_stride,
+                                      osc_planes, trash, channels, fields);
+            break;
+        case kIqCs8:
+            launch_fused_fmt<kIqCs8>(s, b.il, b.il_stride, b.cin, b.last_group, t.fsync, par0, d_sym, sym_stride, d_iq, iq_stride,
+                                     osc_planes, trash, channels, fields);
+            break;
+        default:
+            launch_fused_fmt<kIqCf32>(s, b.il, b.il_stride, b.cin, b.last_group, t.fsync, par0, d_sym, sym_stride, d_iq, iq_stride,
+                                      osc_planes, trash, channels, fields);
+            break;
+    }
 }
 
 }  // namespace atsc_k

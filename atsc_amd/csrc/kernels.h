@@ -79,6 +79,11 @@ hipError_t upload_fft_tables(const float* taps112);
 void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
                          const float* osc_planes, int channels, int fields, int iq_format);
 hipError_t upload_mfma_tables(const float* taps112);
+// The same with the trellis / map / sync stage fused in: symbols are regenerated from b.il + b.cin inside the kernel and
+// never pass through HBM; d_sym (the symbol tap) may be NULL.  Replaces launch_trellis_map + launch_mix_fir_mfma.
+void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
+                          size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
+                          int iq_format);
 constexpr int kMfmaMinChannels = 16;   // below this the 32-wide channel tile of the MFMA form is mostly padding: FFT form
 
 }  // namespace atsc_k

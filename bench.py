@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
     ap.add_argument("--fields", type=int, default=64, help="fields per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--symbol-tap", action="store_true",
+                    help="also write the u8 symbol tap (the parity check point) inside the timed region; the reference's "
+                         "process() hands out IQ only (atsc.cpp:89), so the default workload does not")
     ap.add_argument("--iq-format", choices=("cf32", "cs16", "cs8"), default="cf32",
                     help="IQ sample format of the device sink; cf32 is the reference's payload and the headline "
                          "configuration, cs16/cs8 are the SDR sink formats (SURVEY 8f-3)")
@@ -125,7 +128,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
-        enc.encode_batch(ts.data_ptr(), F, sym.data_ptr(), iq.data_ptr(), stream)
+        enc.encode_batch(ts.data_ptr(), F, sym.data_ptr() if args.symbol_tap else None, iq.data_ptr(), stream)
 
     def barrier():
         if dist is not None:
@@ -191,7 +194,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{C_} channels x {F} fields per GPU per step (BASELINE config 4 per-GPU shard), "
-                               f"TS resident in HBM, symbols + {'complex64' if sample_bytes == 8 else args.iq_format} IQ "
+                               f"TS resident in HBM, {'symbol tap + ' if args.symbol_tap else ''}{'complex64' if sample_bytes == 8 else args.iq_format} IQ "
                                "to a device-resident sink",
                    "channels_per_gpu": C_, "fields_per_step": F, "parallelism": f"channel-sharded x{world}, no collective"},
         "realtime_channels": round(msym_s / SYMBOL_RATE_MSPS, 1),

@@ -127,9 +127,13 @@ size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown form
  * against the same oracle to the same tolerance; their outputs agree to ~5e-7 of full scale but are not bit-identical.
  *   FFT : overlap-save fast convolution on the vector units (any channel count)
  *   MFMA: banded GEMM on the matrix cores; needs the oscillator shared by many channels to pay off
- *   AUTO: MFMA for handles with >= 16 channels and a fixed-point sample format, FFT otherwise (default)
+ *   FUSED: the MFMA form with the trellis / map / sync stage (src/atsc/atsc.cpp:83-84) fused in: the symbols are
+ *         regenerated from the interleaved bytes inside the kernel and never pass through HBM.  Only in
+ *         atsc_hip_encode_batch / _finish with d_iq != NULL; d_sym is then an optional tap (NULL: no symbols are
+ *         written anywhere, atsc_hip_stage_buffer(TRELLIS_MAP) is stale)
+ *   AUTO: FUSED for handles with >= 16 channels, FFT otherwise (default)
  * No reference counterpart (the reference has one scalar/AVX form, filter.h:16-69). */
-enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2 };
+enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2, ATSC_HIP_FIR_FUSED = 3 };
 int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);
 
 /* atsc_hip_process with the radio-side chunking of the reference's transmitter loop (util/atsc_encoder.cpp:84-100:

@@ -526,3 +526,42 @@ def test_mfma_form_sample_formats(torch_cuda):
         raw = d_q.cpu().numpy()
         assert (raw[-4096:] == 0x5A).all()
         assert np.array_equal(raw[:-4096].view(dt).astype(np.float64), _quantize(iq.view(np.float32), full))
+
+
+@pytest.mark.parametrize("C_,nf", [(16, 2), (33, 3), (64, 3), (70, 2)])
+def test_fused_form_bit_identical_to_unfused(torch_cuda, C_, nf):
+    """The fused form regenerates the symbols inside the FIR kernel.  Its symbol tap must equal k_trellis_map's output
+    (and the oracle) bit for bit, and its IQ must equal the unfused matrix-core form's IQ bit for bit (same arithmetic
+    on the same symbols); two consecutive batches exercise the carried state (reserved symbols, carries, field parity)."""
+    torch = torch_cuda
+    per = [ts_mix(700 + c, 2 * nf) for c in range(C_)]
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for form in (atsc_amd.FIR_MFMA, atsc_amd.FIR_FUSED):
+        enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+        enc.set_fir_form(form)
+        n = C_ * nf * FIELD_SYMBOLS
+        res = []
+        for b in range(2):
+            ts = np.concatenate([p[b * nf * FIELD_TS_BYTES:(b + 1) * nf * FIELD_TS_BYTES] for p in per])
+            d_ts = torch.from_numpy(ts).cuda()
+            d_sym = torch.full((n + 4096,), 0xEE, dtype=torch.uint8, device="cuda")
+            d_iq = torch.full((2 * n + 4096,), float("nan"), dtype=torch.float32, device="cuda")
+            enc.encode_batch(d_ts.data_ptr(), nf, d_sym.data_ptr(), d_iq.data_ptr(), st)
+            torch.cuda.synchronize()
+            sym, iq = d_sym.cpu().numpy(), d_iq.cpu().numpy()
+            assert (sym[n:] == 0xEE).all() and np.isnan(iq[2 * n:]).all(), "wrote past the buffers"
+            res.append((sym[:n].reshape(C_, nf, -1), iq[:2 * n].reshape(C_, nf, -1)))
+        outs[form] = res
+    for b in range(2):
+        s_ref, q_ref = outs[atsc_amd.FIR_MFMA][b]
+        s_fus, q_fus = outs[atsc_amd.FIR_FUSED][b]
+        bad = np.argwhere(s_ref != s_fus)
+        assert bad.size == 0, f"batch {b}: {len(bad)} symbol mismatches, first (ch, field, pos) {bad[:5].tolist()}"
+        assert not np.isnan(q_fus).any()
+        assert np.array_equal(q_ref.view(np.uint32), q_fus.view(np.uint32)), f"batch {b}: IQ bits differ"
+    want = Oracle().process_fields(per[C_ - 1], 2 * nf, want=("sym", "iq"))
+    got_sym = np.concatenate([outs[atsc_amd.FIR_FUSED][b][0][C_ - 1].reshape(-1) for b in range(2)])
+    got_iq = np.concatenate([outs[atsc_amd.FIR_FUSED][b][1][C_ - 1].reshape(-1) for b in range(2)])
+    assert np.array_equal(got_sym, want["sym"])
+    assert np.abs(got_iq - want["iq"]).max() <= IQ_TOL
