@@ -343,7 +343,6 @@ void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride,
 // The symbol tap (d_sym) is optional: with it the ring is also copied out, one 128-byte line per channel and group.
 constexpr int kRingRow = 264;                      // bytes per channel row: 256-position ring + 8 (conflict-free b64 reads)
 constexpr int kByteTimes = kFieldCoded / 12;       // 5382 byte-times per field, 207 per part
-constexpr int kFusedRun8 = 16;                     // 128 tiles = 2048 outputs per wave task
 
 // field-relative position of the first data symbol of byte-time g (uniform)
 __device__ __forceinline__ int pos_of_bytetime(int g) {
@@ -358,7 +357,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     const uint8_t* __restrict__ il, size_t il_stride, const uint4* __restrict__ cin, const uint8_t* __restrict__ last_group,
     const uint8_t* __restrict__ fsync, unsigned parity0, uint8_t* __restrict__ sym_out, size_t sym_stride,
     typename OutSample<FMT>::type* __restrict__ iq, size_t iq_stride, const float* __restrict__ planes,
-    typename OutSample<FMT>::type* __restrict__ trash, int channels, int fields, int runs_per_field, int ch_groups) {
+    typename OutSample<FMT>::type* __restrict__ trash, int channels, int fields, int run8, int runs_per_field,
+    int ch_groups) {
     typedef typename OutSample<FMT>::type out_t;
     typedef typename Out2<FMT>::type out2_t;
     __shared__ __align__(16) float s_taps[4 * kTapCopy];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     const int cg = (int)(gidx % ch_groups);
     const int f = (int)(gidx / ch_groups);
     if (f >= fields) return;
-    const int tile0 = run * kFusedRun8 * 8;
+    const int tile0 = run * run8 * 8;
     const int P0 = tile0 * kTile;
 
     // ---- FIR roles (as k_mix_fir_mfma)
@@ -428,19 +428,19 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
         const uint4 ci = cin_c[part0];
         uint32_t acc[3] = {0, 0, 0};
         const int g_lo = part0 * kPartGroups;
-        for (int gq = g_lo + h; gq < next_g; gq += 8) {     // four byte-times per half in flight
-            uint32_t d[4][3];
+        for (int gq = g_lo + h; gq < next_g; gq += 16) {    // eight byte-times per half in flight: the loop is latency-bound
+            uint32_t d[8][3];
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int gg = min(gq + 2 * k4, kByteTimes - 1);
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const int gg = min(gq + 2 * k8, kByteTimes - 1);
                 const uint32_t* src = reinterpret_cast<const uint32_t*>(il_c) + 3 * gg;
-                d[k4][0] = src[0]; d[k4][1] = src[1]; d[k4][2] = src[2];
+                d[k8][0] = src[0]; d[k8][1] = src[1]; d[k8][2] = src[2];
             }
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const int gg = gq + 2 * k4;
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const int gg = gq + 2 * k8;
                 if (gg < next_g) {
-                    const Words3 e = canonical_group(d[k4], gg);
+                    const Words3 e = canonical_group(d[k8], gg);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         uint32_t z2, z0, pr;
@@ -467,15 +467,72 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             rsv[(k + 1) % 3] = ((cinw[k] & 0x01010101u) << 2) | ((pe.w[k] & 0x01010101u) << 1) | ((cinw[k] >> 2) & 0x01010101u);
     }
 
+    // two byte-times: half h takes next_g + h, whose three interleaved dwords are d0..d2
+    auto produce_pair = [&](uint32_t d0, uint32_t d1, uint32_t d2) {
+        const int g = next_g + h;
+        const bool ok = g < kByteTimes;
+        const int gg = ok ? g : kByteTimes - 1;
+        const uint32_t d3[3] = {d0, d1, d2};
+        const Words3 e = canonical_group(d3, gg);
+        uint32_t z2[3], z0[3], pr[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            trellis_local(e.w[k], z2[k], z0[k], pr[k]);
+            if (!ok) pr[k] = 0;
+        }
+        const int pp = gg / kPartGroups, tq = gg - pp * kPartGroups;
+        uint32_t hi[3], zz0[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t other = __shfl_xor(pr[k], 32, 64);
+            const uint32_t cwk = cw[k] ^ (h ? other : 0u);     // half 1 follows half 0's byte-time
+            cw[k] ^= pr[k] ^ other;
+            const uint32_t zz2 = z2[k] ^ ((cwk & 0x01010101u) * 0xAAu);
+            zz0[k] = z0[k] ^ (((cwk >> 1) & 0x01010101u) * 0x44u) ^ (((cwk >> 2) & 0x01010101u) * 0x11u);
+            hi[k] = zz2 | (e.w[k] & 0x55555555u);
+        }
+        if (ok) {
+            // the four symbol times of the byte: segment, place in the segment and commutator phase once per symbol
+            // time, then the three 4-encoder words go to slots (k - phase) mod 3
+            const int t0 = 4 * tq;
+            int sl = t0 / 69, q = t0 - 69 * sl;
+            int m = sl % 3;
+#pragma unroll
+            for (int tau = 0; tau < 4; ++tau) {
+                const int seg = 1 + 12 * pp + sl;
+                const int base = kSegSyms * seg + 4 + 12 * q;
+                if (q == 0) *reinterpret_cast<uint32_t*>(ring + ((kSegSyms * seg) & 255)) = 0x06010106u;
+                const int shb = 6 - 2 * tau;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t v = (((hi[k] >> shb) & 0x03030303u) << 1) | ((zz0[k] >> shb) & 0x01010101u);
+                    int hslot = k - m;
+                    hslot += hslot < 0 ? 3 : 0;
+                    *reinterpret_cast<uint32_t*>(ring + ((base + 4 * hslot) & 255)) = v;
+                }
+                if (++q == 69) { q = 0; ++sl; m = m == 2 ? 0 : m + 1; }
+            }
+        }
+        next_g += 2;
+        if (next_g >= kByteTimes) {
+            fs_j = 0; fs_base = kFieldSyms; prod_pos = kFieldSyms;    // behind the field: the copy of its sync head
+        } else {
+            prod_pos = pos_of_bytetime(next_g) - 4;
+        }
+    };
+
     // everything below `limit` (extended position) into the ring
-    auto produce_until = [&](int limit) {
+    // (the first `npre` pairs of byte-times take their interleaved dwords from the prefetch registers)
+    auto produce_until = [&](int limit, int npre, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1,
+                             uint32_t b2) {
+        int it = 0;
         while (prod_pos < limit) {
             if (fs_j >= 0) {
                 // field-sync segment: the table, its last three dwords replaced by the reserved symbols; both halves
                 // of a channel's lane pair write alternate dwords
                 const int n = min(kSegSyms - fs_j, ((limit - prod_pos) + 3) & ~3);
                 for (int d = (fs_j >> 2) + h; d < ((fs_j + n) >> 2); d += 2) {
-                    const uint32_t v = d >= 205 ? rsv[d - 205] : fs_tab[d];
+                    const uint32_t v = d < 205 ? fs_tab[d] : (d == 205 ? rsv[0] : (d == 206 ? rsv[1] : rsv[2]));
                     *reinterpret_cast<uint32_t*>(ring + ((fs_base + 4 * d) & 255)) = v;
                 }
                 fs_j += n;
@@ -487,49 +544,15 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                 }
                 continue;
             }
-            // two byte-times: half h takes next_g + h
-            const int g = next_g + h;
-            const bool ok = g < kByteTimes;
-            const int gg = ok ? g : kByteTimes - 1;
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(il_c) + 3 * gg;
-            const uint32_t d3[3] = {src[0], src[1], src[2]};
-            const Words3 e = canonical_group(d3, gg);
-            uint32_t z2[3], z0[3], pr[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                trellis_local(e.w[k], z2[k], z0[k], pr[k]);
-                if (!ok) pr[k] = 0;
-            }
-            const int pp = gg / kPartGroups, tq = gg - pp * kPartGroups;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const uint32_t other = __shfl_xor(pr[k], 32, 64);
-                const uint32_t cwk = cw[k] ^ (h ? other : 0u);     // half 1 follows half 0's byte-time
-                cw[k] ^= pr[k] ^ other;
-                if (ok) {
-                    const uint32_t zz2 = z2[k] ^ ((cwk & 0x01010101u) * 0xAAu);
-                    const uint32_t zz0 = z0[k] ^ (((cwk >> 1) & 0x01010101u) * 0x44u) ^ (((cwk >> 2) & 0x01010101u) * 0x11u);
-                    const uint32_t hi = zz2 | (e.w[k] & 0x55555555u);
-#pragma unroll
-                    for (int tau = 0; tau < 4; ++tau) {
-                        const int shb = 6 - 2 * tau;
-                        const uint32_t v = (((hi >> shb) & 0x03030303u) << 1) | ((zz0 >> shb) & 0x01010101u);
-                        const int t = 4 * tq + tau;
-                        const int sl = t / 69, q = t - 69 * sl;
-                        const int seg = 1 + 12 * pp + sl;
-                        const int hslot = (k + 3 - sl % 3) % 3;
-                        const int pos = kSegSyms * seg + 4 + 12 * q + 4 * hslot;
-                        *reinterpret_cast<uint32_t*>(ring + (pos & 255)) = v;
-                        if (k == 0 && q == 0) *reinterpret_cast<uint32_t*>(ring + ((kSegSyms * seg) & 255)) = 0x06010106u;
-                    }
-                }
-            }
-            next_g += 2;
-            if (next_g >= kByteTimes) {
-                fs_j = 0; fs_base = kFieldSyms; prod_pos = kFieldSyms;    // behind the field: the copy of its sync head
+            uint32_t d0, d1, d2;
+            if (it < npre) {
+                d0 = it ? b0 : a0; d1 = it ? b1 : a1; d2 = it ? b2 : a2;
             } else {
-                prod_pos = pos_of_bytetime(next_g) - 4;
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(next_g + h, kByteTimes - 1);
+                d0 = src[0]; d1 = src[1]; d2 = src[2];
             }
+            ++it;
+            produce_pair(d0, d1, d2);
         }
     };
 
@@ -550,7 +573,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     };
 
     // ---- prime: symbols [P0, P0 + 112) for K-steps 0..6 of the first tile
-    produce_until(P0 + 112);
+    produce_until(P0 + 112, 0, 0, 0, 0, 0, 0, 0);
     lds_order();
     h8 bw[kKSteps][1];
 #pragma unroll
@@ -558,7 +581,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
         bw[ks][0] = levels8(*reinterpret_cast<const uint2*>(ring + ((P0 + 16 * ks + 8 * h) & 255)));
     if (run == 0) tap(0, 7);         // [0, 112): the field's first symbols, which no group's tap covers
     lds_order();
-    produce_until(P0 + 240 + 16);
+    produce_until(P0 + 240 + 16, 0, 0, 0, 0, 0, 0, 0);
     lds_order();
 
     float4 pre_re, pre_im;
@@ -566,10 +589,17 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     *reinterpret_cast<float4*>(pre_dst) = pre_re;
     *reinterpret_cast<float4*>(pre_dst + 256) = pre_im;
     lds_order();
-    for (int t8 = 0; t8 < kFusedRun8; ++t8) {
+    for (int t8 = 0; t8 < run8; ++t8) {
         const float* ow = ow0 + 512 * (t8 & 1);
         const int Tg = tile0 + 8 * t8;
         osc_fetch(Tg + 8, pre_re, pre_im);
+        // The interleaved bytes of the next four byte-times are fetched now and used at the group's last tile: their
+        // latency hides behind seven tiles, and the (in-order) wait for them does not reach this group's IQ stores.
+        const uint32_t* ia = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(next_g + h, kByteTimes - 1);
+        const uint32_t* ib = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(next_g + 2 + h, kByteTimes - 1);
+        const uint32_t a0 = ia[0], a1 = ia[1], a2 = ia[2], b0 = ib[0], b1 = ib[1], b2 = ib[2];
+        const bool pre_ok = fs_j < 0;
+        __builtin_amdgcn_sched_barrier(0);
         if (Tg < kTilesPerField) tap(16 * Tg + 112, 8);   // [16Tg + 112, 16Tg + 240): produced, not yet overwritten
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -580,7 +610,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             if (u == 7) {
                 // tile 7 has taken its symbols: the ring may advance to what the next group needs
                 lds_order();
-                produce_until(16 * (Tg + 8) + 240 + 16);
+                const int limit = 16 * (Tg + 8) + 240 + 16;
+                // (the prefetch is valid only if the group starts producing byte-times, not field sync)
+                produce_until(limit, pre_ok ? 2 : 0, a0, a1, a2, b0, b1, b2);
                 float* d = pre_dst + 512 * ((t8 + 1) & 1);
                 *reinterpret_cast<float4*>(d) = pre_re;
                 *reinterpret_cast<float4*>(d + 256) = pre_im;
@@ -641,13 +673,21 @@ static void launch_fused_fmt(hipStream_t s, const uint8_t* il, size_t il_stride,
                              const uint8_t* fsync, unsigned parity0, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                              size_t iq_stride, const float* planes, void* trash, int channels, int fields) {
     typedef typename OutSample<FMT>::type out_t;
-    const int runs = (kTilesPerField + 8 * kFusedRun8 - 1) / (8 * kFusedRun8);
+    static const int run8_env = [] { const char* e = getenv("ATSC_FUSED_RUN8"); return e ? atoi(e) : 0; }();
     const int ch_groups = (channels + 31) / 32;
+    // Long runs amortise the carry prefix at a run's start (up to 206 byte-times re-read); short runs balance the grid:
+    // the longest run that still leaves two rounds of wave tasks for the chip's 2048 wave slots at this occupancy.
+    int run8 = run8_env;
+    if (run8 <= 0) {
+        run8 = 64;
+        while (run8 > 8 && (long)((kTilesPerField + 8 * run8 - 1) / (8 * run8)) * ch_groups * fields < 2 * 2048) run8 >>= 1;
+    }
+    const int runs = (kTilesPerField + 8 * run8 - 1) / (8 * run8);
     const long tasks = (long)runs * ch_groups * fields;
     const unsigned grid = (unsigned)((tasks + kMfmaWaves - 1) / kMfmaWaves);
     hipLaunchKernelGGL((k_mix_fir_fused<FMT>), dim3(grid), dim3(64 * kMfmaWaves), 0, s, il, il_stride, cin, last_group, fsync,
                        parity0, d_sym, sym_stride, static_cast<out_t*>(d_iq), iq_stride, planes, static_cast<out_t*>(trash),
-                       channels, fields, runs, ch_groups);
+                       channels, fields, run8, runs, ch_groups);
 }
 
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,

@@ -115,7 +115,11 @@ def main():
     fmt = {"cf32": atsc_amd.IQ_CF32, "cs16": atsc_amd.IQ_CS16, "cs8": atsc_amd.IQ_CS8}[args.iq_format]
     sample_bytes = {"cf32": 8, "cs16": 4, "cs8": 2}[args.iq_format]
     enc.set_iq_format(fmt)
-    fir_bytes_per_sym = 1.0 + sample_bytes          # 9.0 for the reference's complex64 payload
+    # Handles with >= 16 channels run the fused kernel (trellis/map/sync + mixer + FIR on the matrix cores): it reads the
+    # interleaved bytes (64584 B per field = 0.248 B/symbol) and writes the IQ; the symbols never pass through HBM.
+    # Fewer channels: the FFT form behind k_trellis_map, 1 B symbol in + IQ out (9.0 B/symbol for complex64).
+    fused = C_ >= 16 and os.environ.get("ATSC_FIR_FORM", "fused") == "fused"
+    fir_bytes_per_sym = (64584.0 / atsc_amd.FIELD_SYMBOLS if fused else 1.0) + sample_bytes
     # synthetic 19.39 Mbps TS per channel: PRBS payload behind a 0x47 sync byte, seeded per global channel
     g = torch.Generator(device="cuda")
     g.manual_seed(1234 + rank)
@@ -175,7 +179,8 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-        if tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8:
+        if tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8 and \
+                ("fused" in tj.get("kernel", "")) == fused:
             traffic = tj["traffic_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         pass
@@ -201,7 +206,9 @@ def main():
         "realtime_channels_per_gpu": round(msym_s / SYMBOL_RATE_MSPS / world, 1),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "roofline": {
-            "kernel": "k_mix_fir_fft (pilot/offset mixer + 112-tap RRC FIR, overlap-save 1024-point FFT form)",
+            "kernel": ("k_mix_fir_fused (precoder/trellis/mapper/sync + pilot/offset mixer + 112-tap RRC FIR as a banded "
+                       "fp16 hi/lo GEMM on the matrix cores, symbols regenerated in LDS)" if fused else
+                       "k_mix_fir_fft (pilot/offset mixer + 112-tap RRC FIR, overlap-save 1024-point FFT form)"),
             "bound": "hbm",
             "achieved": round(fir_gbs, 1),
             "peak": HBM_PEAK_GBS,
@@ -210,7 +217,9 @@ def main():
             "traffic": traffic,
             "algorithmic_bytes_per_launch": fir_bytes_per_sym * sym_per_step_gpu,
             "avg_launch_ms": round(stage_ms["mix_fir"], 4),
-            "note": f"algorithmic bytes = {fir_bytes_per_sym:g} B/symbol (1 B symbol in + {sample_bytes} B {args.iq_format} out, SURVEY 8d); the measured "
+            "note": f"algorithmic bytes = {fir_bytes_per_sym:.3f} B/symbol ("
+                    + ("0.248 B interleaved bytes in" if fused else "1 B symbol in")
+                    + f" + {sample_bytes} B {args.iq_format} out, SURVEY 8d); the measured "
                     "ceiling of this part for the same traffic mix without any compute (8.5 GB written beside a 1 GB read stream, "
                     "scripts/ubench/mix_bw.hip) is 2.08 ms = 4.6 TB/s, i.e. frac <= ~0.58; "
                     "PMC traffic per launch: profiles/",
