@@ -49,7 +49,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 constexpr int kTile = 16;                          // outputs per tile = one MFMA K-step
 constexpr int kTilesPerField = kFieldSyms / kTile; // 16276
 constexpr int kKSteps = 8;                         // 128 >= 16 + 110 inputs feed a tile
-constexpr int kTapCopy = 176;                      // floats per shifted copy of the padded tap array
+constexpr int kTapCopy = 144;                      // floats per shifted copy of the padded tap array
 constexpr int kTapLead = 16;                       // zeros ahead of tap 0 (p <= 15)
 constexpr float kWScale = 65536.0f;                // weights are scaled into fp16's normal range; exact to undo
 constexpr int kStageRow = 36;                      // floats per channel row of the output image (32 + 4: conflict-free b128)
@@ -118,7 +118,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_mfma(const uint8
     for (int i = tid; i < 4 * kTapCopy; i += 64 * kMfmaWaves) s_taps[i] = g_taps_mfma[i];
     __syncthreads();
 
-    const int lane = tid & 63, wv = tid >> 6;
+    // the wave index is made scalar: task, field, tile and every loop bound below are then wave-uniform SGPR values
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // task = (channel group, run, field); neighbouring waves take neighbouring runs of one field (shared oscillator lines)
     const long task = (long)blockIdx.x * kMfmaWaves + wv;
@@ -362,14 +363,16 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     typedef typename OutSample<FMT>::type out_t;
     typedef typename Out2<FMT>::type out2_t;
     __shared__ __align__(16) float s_taps[4 * kTapCopy];
-    __shared__ __align__(16) float s_stage[kMfmaWaves][32 * kStageRow];
+    // 53.5 KB per block: three blocks = 12 waves per CU (3 per SIMD at <= 168 VGPRs)
+    __shared__ __align__(16) float s_stage[kMfmaWaves][16 * kStageRow];    // output image of 16 channels at a time
     __shared__ __align__(16) uint8_t s_ring[kMfmaWaves][32 * kRingRow];
-    __shared__ __align__(16) float s_osc[kMfmaWaves][2][2][256];
+    __shared__ __align__(16) float s_osc[kMfmaWaves][2][256];              // [re | im] of positions i_group .. +255
     const int tid_ = threadIdx.x;
     for (int i = tid_; i < 4 * kTapCopy; i += 64 * kMfmaWaves) s_taps[i] = g_taps_mfma[i];
     __syncthreads();
 
-    const int lane = tid_ & 63, wv = tid_ >> 6;
+    // the wave index is made scalar: task, field, tile, byte-time counters and every loop bound below are wave-uniform
+    const int lane = tid_ & 63, wv = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     const int r = lane & 31, h = lane >> 5;
     const long task = (long)blockIdx.x * kMfmaWaves + wv;
     const int run = (int)(task % runs_per_field);
@@ -383,18 +386,29 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     // ---- FIR roles (as k_mix_fir_mfma)
     const int p = r >> 1, comp = r & 1;
     const int sh = (4 - (p & 3)) & 3;
-    const float* tapp = s_taps + sh * kTapCopy + (kTapLead + 8 * h - p - sh);
-    const float* ow0 = s_osc[wv][0][comp] + 8 * h;
+    // The 8 x 8 taps of this lane do not depend on the tile: registers for the whole run.  (Read from LDS per K-step they
+    // are 16 of the ~50 LDS instructions of a tile, the only ones with bank conflicts, and the LDS pipe -- 70-90 % busy --
+    // is what bounds this kernel's arithmetic phase.)
+    float4 tapr[kKSteps][2];
+    {
+        const float* tapp = s_taps + sh * kTapCopy + (kTapLead + 8 * h - p - sh);
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            tapr[ks][0] = *reinterpret_cast<const float4*>(tapp + 16 * ks);
+            tapr[ks][1] = *reinterpret_cast<const float4*>(tapp + 16 * ks + 4);
+        }
+    }
+    const float* ow = s_osc[wv][comp] + 8 * h;                                  // + 16*u + 16*ks, + j
     const float* pre_src = planes + (size_t)f * 2 * kPaddedSyms + 4 * lane;
-    float* pre_dst = s_osc[wv][0][0] + 4 * lane;
+    float* pre_dst = s_osc[wv][0] + 4 * lane;                                   // re at +0, im at +256
     auto osc_fetch = [&](int tile_first, float4& a, float4& b) {
         const int i = (tile_first < kTilesPerField ? tile_first : 0) * kTile;
         a = *reinterpret_cast<const float4*>(pre_src + i);
         b = *reinterpret_cast<const float4*>(pre_src + kPaddedSyms + i);
     };
     float* stage = s_stage[wv];
-    float* st_w = stage + r * kStageRow + 4 * h;
-    const float* st_r = stage + (lane >> 3) * kStageRow + 4 * (lane & 7);
+    float* st_w = stage + (r & 15) * kStageRow + 4 * h;                         // + 8*g: outputs 4g+2h, 4g+2h+1 of channel r
+    const float* st_r = stage + (lane >> 3) * kStageRow + 4 * (lane & 7);       // + 8*q rows
 
     // ---- symbol producer: lane = (channel r, half h)
     const int ch = min(cg * 32 + r, channels - 1);          // channels past the end recompute the last one; never stored
@@ -590,11 +604,12 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     *reinterpret_cast<float4*>(pre_dst + 256) = pre_im;
     lds_order();
     for (int t8 = 0; t8 < run8; ++t8) {
-        const float* ow = ow0 + 512 * (t8 & 1);
         const int Tg = tile0 + 8 * t8;
-        osc_fetch(Tg + 8, pre_re, pre_im);
-        // The interleaved bytes of the next four byte-times are fetched now and used at the group's last tile: their
-        // latency hides behind seven tiles, and the (in-order) wait for them does not reach this group's IQ stores.
+        // The interleaved bytes of the next four byte-times are fetched NOW and used at the group's last tile.  vmcnt
+        // completes in order: a load issued at production time would make the wave wait for every IQ store of the group
+        // before it (that drain cost 0.6 ms per launch); a load issued here only waits for the previous group's stores,
+        // seven tile times old.  The two pairs are consumed by a fixed two-trip loop without loads so that the
+        // compiler's wait is an exact count.
         const uint32_t* ia = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(next_g + h, kByteTimes - 1);
         const uint32_t* ib = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(next_g + 2 + h, kByteTimes - 1);
         const uint32_t a0 = ia[0], a1 = ia[1], a2 = ia[2], b0 = ib[0], b1 = ib[1], b2 = ib[2];
@@ -607,15 +622,15 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             const bool tile_ok = tile < kTilesPerField;
             const int i0 = tile * kTile;
             bw[(u + kKSteps - 1) & 7][0] = levels8(*reinterpret_cast<const uint2*>(ring + ((i0 + 112 + 8 * h) & 255)));
+            if (u == 5) osc_fetch(Tg + 8, pre_re, pre_im);   // next group's oscillator window, parked two tiles later
             if (u == 7) {
                 // tile 7 has taken its symbols: the ring may advance to what the next group needs
                 lds_order();
                 const int limit = 16 * (Tg + 8) + 240 + 16;
-                // (the prefetch is valid only if the group starts producing byte-times, not field sync)
-                produce_until(limit, pre_ok ? 2 : 0, a0, a1, a2, b0, b1, b2);
-                float* d = pre_dst + 512 * ((t8 + 1) & 1);
-                *reinterpret_cast<float4*>(d) = pre_re;
-                *reinterpret_cast<float4*>(d + 256) = pre_im;
+#pragma unroll 1
+                for (int it = 0; it < 2; ++it)
+                    if (pre_ok && fs_j < 0 && prod_pos < limit) produce_pair(it ? b0 : a0, it ? b1 : a1, it ? b2 : a2);
+                produce_until(limit, 0, 0, 0, 0, 0, 0, 0);   // field sync, field end, a third pair at a segment boundary
             }
             f16v acc;
 #pragma unroll
@@ -623,8 +638,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             auto weights = [&](int ks, h8& ahi, h8& alo) {
                 const float4 o0 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks);
                 const float4 o1 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks + 4);
-                const float4 c0 = *reinterpret_cast<const float4*>(tapp + 16 * ks);
-                const float4 c1 = *reinterpret_cast<const float4*>(tapp + 16 * ks + 4);
+                const float4 c0 = tapr[ks][0], c1 = tapr[ks][1];
                 const float x[8] = {c0.x * o0.x, c0.y * o0.y, c0.z * o0.z, c0.w * o0.w,
                                     c1.x * o1.x, c1.y * o1.y, c1.z * o1.z, c1.w * o1.w};
 #pragma unroll
@@ -636,29 +650,42 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                     alo[j] = ll.x; alo[j + 1] = ll.y;
                 }
             };
-            h8 ahi[2], alo[2];
-            weights(0, ahi[0], alo[0]);
+            // (one weight buffer: at 3 waves per SIMD the other waves cover the generation latency; a second buffer costs the
+            // 16 registers that decide the occupancy)
 #pragma unroll
             for (int ks = 0; ks < kKSteps; ++ks) {
-                const int cur = ks & 1;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[cur], bw[(u + ks) & 7][0], acc, 0, 0, 0);
-                if (ks + 1 < kKSteps) weights(ks + 1, ahi[cur ^ 1], alo[cur ^ 1]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[cur], bw[(u + ks) & 7][0], acc, 0, 0, 0);
+                h8 ahi, alo;
+                weights(ks, ahi, alo);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bw[(u + ks) & 7][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bw[(u + ks) & 7][0], acc, 0, 0, 0);
             }
-            {
-                constexpr float inv = 1.0f / kWScale;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq)
-                    *reinterpret_cast<float4*>(st_w + 8 * gq) =
-                        make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv);
+            if (u == 7) {
+                // the group's last read of the oscillator window is issued: the next group's window replaces it
                 lds_order();
-                const int cbase = cg * 32 + (lane >> 3);
+                *reinterpret_cast<float4*>(pre_dst) = pre_re;
+                *reinterpret_cast<float4*>(pre_dst + 256) = pre_im;
+            }
+            // C -> LDS image -> whole 128-byte lines, 16 channels at a time (the image is what bounds the LDS per wave)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                constexpr float inv = 1.0f / kWScale;
+                if ((r >> 4) == half) {
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq)
+                        *reinterpret_cast<float4*>(st_w + 8 * gq) =
+                            make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv);
+                }
+                lds_order();
+                const int cbase = cg * 32 + 16 * half + (lane >> 3);
                 out_t* dst = iq + (size_t)f * kFieldSyms + i0 + 2 * (lane & 7);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 2; ++q) {
                     const float4 v = *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow);
                     const int c = cbase + 8 * q;
                     out_t* d = (tile_ok && c < channels) ? dst + (size_t)c * iq_stride : trash + 2 * lane;
+#ifdef ATSC_FUSED_TRASH   // timing experiment: compute floor (every store into the cache-resident trash area)
+                    d = trash + 2 * lane;
+#endif
                     *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
                 }
                 lds_order();
@@ -676,11 +703,11 @@ static void launch_fused_fmt(hipStream_t s, const uint8_t* il, size_t il_stride,
     static const int run8_env = [] { const char* e = getenv("ATSC_FUSED_RUN8"); return e ? atoi(e) : 0; }();
     const int ch_groups = (channels + 31) / 32;
     // Long runs amortise the carry prefix at a run's start (up to 206 byte-times re-read); short runs balance the grid:
-    // the longest run that still leaves two rounds of wave tasks for the chip's 2048 wave slots at this occupancy.
+    // the longest run that still leaves two rounds of wave tasks for the chip's 3072 wave slots (3 per SIMD).
     int run8 = run8_env;
     if (run8 <= 0) {
         run8 = 64;
-        while (run8 > 8 && (long)((kTilesPerField + 8 * run8 - 1) / (8 * run8)) * ch_groups * fields < 2 * 2048) run8 >>= 1;
+        while (run8 > 8 && (long)((kTilesPerField + 8 * run8 - 1) / (8 * run8)) * ch_groups * fields < 2 * 3072) run8 >>= 1;
     }
     const int runs = (kTilesPerField + 8 * run8 - 1) / (8 * run8);
     const long tasks = (long)runs * ch_groups * fields;
