@@ -235,7 +235,7 @@ int run_back(atsc_hip_encoder* e, const uint4* carry_xor, int fields, uint8_t* d
 }
 
 // which form of the mixer + FIR this batch runs (include/atsc_hip.h, atsc_hip_set_fir_form)
-int resolve_fir_form(const atsc_hip_encoder* e) {
+int resolve_fir_form(const atsc_hip_encoder* e, bool want_symbols = false) {
     static const int form_env = [] {
         const char* v = getenv("ATSC_FIR_FORM");   // A/B runs: overrides the handle's setting
         if (!v) return 0;
@@ -246,7 +246,9 @@ int resolve_fir_form(const atsc_hip_encoder* e) {
     }();
     const int form = form_env ? form_env : e->fir_form;
     if (form != ATSC_HIP_FIR_AUTO) return form;
-    if (e->cfg.channels >= kMfmaMinChannels) return ATSC_HIP_FIR_FUSED;
+    // the fused kernel pays off when the symbols need not exist in HBM; with the symbol tap requested the separate
+    // k_trellis_map + FFT form is faster (measured 3.19 vs 3.64 ms per 64 x 64 step)
+    if (e->cfg.channels >= kMfmaMinChannels && !want_symbols) return ATSC_HIP_FIR_FUSED;
     return ATSC_HIP_FIR_FFT;
 }
 
@@ -312,7 +314,7 @@ extern "C" int atsc_hip_encode_finish(atsc_hip_encoder* e, const void* d_carry_x
     e->last_fields = fields;
     const size_t sym_stride = (size_t)fields * kFieldSyms;
     int rc;
-    if (d_iq && resolve_fir_form(e) == ATSC_HIP_FIR_FUSED) {
+    if (d_iq && resolve_fir_form(e, d_sym != nullptr) == ATSC_HIP_FIR_FUSED) {
         // carries, then ONE kernel for trellis / map / sync / mixer / FIR: the symbols never pass through HBM; the symbol
         // tap is written only if the caller asked for it (d_sym)
         mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);

@@ -118,7 +118,7 @@ def main():
     # Handles with >= 16 channels run the fused kernel (trellis/map/sync + mixer + FIR on the matrix cores): it reads the
     # interleaved bytes (64584 B per field = 0.248 B/symbol) and writes the IQ; the symbols never pass through HBM.
     # Fewer channels: the FFT form behind k_trellis_map, 1 B symbol in + IQ out (9.0 B/symbol for complex64).
-    fused = C_ >= 16 and os.environ.get("ATSC_FIR_FORM", "fused") == "fused"
+    fused = C_ >= 16 and not args.symbol_tap and os.environ.get("ATSC_FIR_FORM", "fused") == "fused"
     fir_bytes_per_sym = (64584.0 / atsc_amd.FIELD_SYMBOLS if fused else 1.0) + sample_bytes
     # synthetic 19.39 Mbps TS per channel: PRBS payload behind a 0x47 sync byte, seeded per global channel
     g = torch.Generator(device="cuda")
@@ -220,8 +220,8 @@ def main():
             "note": f"algorithmic bytes = {fir_bytes_per_sym:.3f} B/symbol ("
                     + ("0.248 B interleaved bytes in" if fused else "1 B symbol in")
                     + f" + {sample_bytes} B {args.iq_format} out, SURVEY 8d); the measured "
-                    "ceiling of this part for the same traffic mix without any compute (8.5 GB written beside a 1 GB read stream, "
-                    "scripts/ubench/mix_bw.hip) is 2.08 ms = 4.6 TB/s, i.e. frac <= ~0.58; "
+                    "ceiling of this part without any compute is 1.5-1.7 ms for the pure 8.5 GB write stream and 2.08 ms with a "
+                    "1 GB read stream beside it (scripts/ubench/write_bw.hip, mix_bw.hip), i.e. frac <= ~0.6-0.7; "
                     "PMC traffic per launch: profiles/",
             "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes) * msym_s * 1e6 / world / 1e9, 1),
         },
