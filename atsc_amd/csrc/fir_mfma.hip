@@ -610,9 +610,16 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
         // before it (that drain cost 0.6 ms per launch); a load issued here only waits for the previous group's stores,
         // seven tile times old.  The two pairs are consumed by a fixed two-trip loop without loads so that the
         // compiler's wait is an exact count.
+#ifndef ATSC_FUSED_NOLOADS
+        osc_fetch(Tg + 8, pre_re, pre_im);             // next group's oscillator window, parked after this group's last tile
+#endif
         const uint32_t* ia = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(next_g + h, kByteTimes - 1);
         const uint32_t* ib = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(next_g + 2 + h, kByteTimes - 1);
+#ifdef ATSC_FUSED_NOLOADS   // timing experiment: no global loads in the steady state
+        const uint32_t a0 = (uint32_t)(size_t)ia, a1 = a0 * 3, a2 = a0 * 5, b0 = (uint32_t)(size_t)ib, b1 = b0 * 3, b2 = b0 * 7;
+#else
         const uint32_t a0 = ia[0], a1 = ia[1], a2 = ia[2], b0 = ib[0], b1 = ib[1], b2 = ib[2];
+#endif
         const bool pre_ok = fs_j < 0;
         __builtin_amdgcn_sched_barrier(0);
         if (Tg < kTilesPerField) tap(16 * Tg + 112, 8);   // [16Tg + 112, 16Tg + 240): produced, not yet overwritten
@@ -622,7 +629,6 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             const bool tile_ok = tile < kTilesPerField;
             const int i0 = tile * kTile;
             bw[(u + kKSteps - 1) & 7][0] = levels8(*reinterpret_cast<const uint2*>(ring + ((i0 + 112 + 8 * h) & 255)));
-            if (u == 5) osc_fetch(Tg + 8, pre_re, pre_im);   // next group's oscillator window, parked two tiles later
             if (u == 7) {
                 // tile 7 has taken its symbols: the ring may advance to what the next group needs
                 lds_order();
@@ -683,6 +689,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                     const float4 v = *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow);
                     const int c = cbase + 8 * q;
                     out_t* d = (tile_ok && c < channels) ? dst + (size_t)c * iq_stride : trash + 2 * lane;
+#ifdef ATSC_FUSED_CONTIG   // timing experiment: same bytes as [field][tile][channel][16 samples], 1 KB contiguous per store
+                    d = iq + (((size_t)f * kTilesPerField + min(tile, kTilesPerField - 1)) * channels + min(c, channels - 1)) * 16 + 2 * (lane & 7);
+#endif
 #ifdef ATSC_FUSED_TRASH   // timing experiment: compute floor (every store into the cache-resident trash area)
                     d = trash + 2 * lane;
 #endif
