@@ -243,13 +243,19 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_mfma(const uint8
                 const float4 o1 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks + 4);
                 const float4 c0 = *reinterpret_cast<const float4*>(tapp + 16 * ks);
                 const float4 c1 = *reinterpret_cast<const float4*>(tapp + 16 * ks + 4);
-                const float x[8] = {c0.x * o0.x, c0.y * o0.y, c0.z * o0.z, c0.w * o0.w,
-                                    c1.x * o1.x, c1.y * o1.y, c1.z * o1.z, c1.w * o1.w};
+                // packed products (v_pk_mul_f32: two per instruction, same rounding as the scalar form)
+                const v2f_t xa = (v2f_t){c0.x, c0.y} * (v2f_t){o0.x, o0.y}, xb = (v2f_t){c0.z, c0.w} * (v2f_t){o0.z, o0.w};
+                const v2f_t xc = (v2f_t){c1.x, c1.y} * (v2f_t){o1.x, o1.y}, xd = (v2f_t){c1.z, c1.w} * (v2f_t){o1.z, o1.w};
+                const float x[8] = {xa.x, xa.y, xb.x, xb.y, xc.x, xc.y, xd.x, xd.y};
+                const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                const float oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     const h2 hh = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]));
+                    // residual of the exact product (one fused multiply-add with the fp16 operand converted in the instruction)
                     const h2 ll = __builtin_bit_cast(
-                        h2, __builtin_amdgcn_cvt_pkrtz(x[j] - (float)hh.x, x[j + 1] - (float)hh.y));
+                        h2, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(cc[j], oo[j], -(float)hh.x),
+                                                       __builtin_fmaf(cc[j + 1], oo[j + 1], -(float)hh.y)));
                     ahi[j] = hh.x; ahi[j + 1] = hh.y;
                     alo[j] = ll.x; alo[j + 1] = ll.y;
                 }
@@ -633,6 +639,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                 // tile 7 has taken its symbols: the ring may advance to what the next group needs
                 lds_order();
                 const int limit = 16 * (Tg + 8) + 240 + 16;
+#ifdef ATSC_FUSED_NOCOMPUTE
+                prod_pos = 1 << 30;
+#endif
 #pragma unroll 1
                 for (int it = 0; it < 2; ++it)
                     if (pre_ok && fs_j < 0 && prod_pos < limit) produce_pair(it ? b0 : a0, it ? b1 : a1, it ? b2 : a2);
@@ -645,19 +654,28 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                 const float4 o0 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks);
                 const float4 o1 = *reinterpret_cast<const float4*>(ow + 16 * u + 16 * ks + 4);
                 const float4 c0 = tapr[ks][0], c1 = tapr[ks][1];
-                const float x[8] = {c0.x * o0.x, c0.y * o0.y, c0.z * o0.z, c0.w * o0.w,
-                                    c1.x * o1.x, c1.y * o1.y, c1.z * o1.z, c1.w * o1.w};
+                // packed products (v_pk_mul_f32: two per instruction, same rounding as the scalar form)
+                const v2f_t xa = (v2f_t){c0.x, c0.y} * (v2f_t){o0.x, o0.y}, xb = (v2f_t){c0.z, c0.w} * (v2f_t){o0.z, o0.w};
+                const v2f_t xc = (v2f_t){c1.x, c1.y} * (v2f_t){o1.x, o1.y}, xd = (v2f_t){c1.z, c1.w} * (v2f_t){o1.z, o1.w};
+                const float x[8] = {xa.x, xa.y, xb.x, xb.y, xc.x, xc.y, xd.x, xd.y};
+                const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                const float oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     const h2 hh = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x[j], x[j + 1]));
+                    // residual of the exact product (one fused multiply-add with the fp16 operand converted in the instruction)
                     const h2 ll = __builtin_bit_cast(
-                        h2, __builtin_amdgcn_cvt_pkrtz(x[j] - (float)hh.x, x[j + 1] - (float)hh.y));
+                        h2, __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf(cc[j], oo[j], -(float)hh.x),
+                                                       __builtin_fmaf(cc[j + 1], oo[j + 1], -(float)hh.y)));
                     ahi[j] = hh.x; ahi[j + 1] = hh.y;
                     alo[j] = ll.x; alo[j + 1] = ll.y;
                 }
             };
             // (one weight buffer: at 3 waves per SIMD the other waves cover the generation latency; a second buffer costs the
             // 16 registers that decide the occupancy)
+#ifdef ATSC_FUSED_NOCOMPUTE   // timing experiment: the store stream alone, in this kernel's own structure
+            for (int e = 0; e < 4; ++e) acc[e] = (float)bw[(u + e) & 7][0][e];
+#else
 #pragma unroll
             for (int ks = 0; ks < kKSteps; ++ks) {
                 h8 ahi, alo;
@@ -665,6 +683,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bw[(u + ks) & 7][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bw[(u + ks) & 7][0], acc, 0, 0, 0);
             }
+#endif
             if (u == 7) {
                 // the group's last read of the oscillator window is issued: the next group's window replaces it
                 lds_order();
@@ -695,6 +714,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
 #ifdef ATSC_FUSED_TRASH   // timing experiment: compute floor (every store into the cache-resident trash area)
                     d = trash + 2 * lane;
 #endif
+#ifdef ATSC_FUSED_NOSTORE   // timing experiment: no store is executed (the condition is never true, the compiler cannot know)
+                    if (channels < 0)
+#endif
                     *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
                 }
                 lds_order();
@@ -711,12 +733,18 @@ static void launch_fused_fmt(hipStream_t s, const uint8_t* il, size_t il_stride,
     typedef typename OutSample<FMT>::type out_t;
     static const int run8_env = [] { const char* e = getenv("ATSC_FUSED_RUN8"); return e ? atoi(e) : 0; }();
     const int ch_groups = (channels + 31) / 32;
-    // Long runs amortise the carry prefix at a run's start (up to 206 byte-times re-read); short runs balance the grid:
-    // the longest run that still leaves two rounds of wave tasks for the chip's 3072 wave slots (3 per SIMD).
+    // Long runs amortise what a run pays at its start (carry prefix of up to 206 byte-times, priming the ring: about 12
+    // tile times); short runs balance the grid.  The chip holds 2048 of these waves at once (2 per SIMD), so a launch takes
+    // about ceil(tasks / 2048) rounds of (run length + 12) tile times: the run length that minimises that (measured, 64
+    // channels x 64 fields: 2.39 ms at 128 groups per run = one round, 2.43 at 64, 2.48 at 32, 2.61 at 16).
     int run8 = run8_env;
     if (run8 <= 0) {
-        run8 = 64;
-        while (run8 > 8 && (long)((kTilesPerField + 8 * run8 - 1) / (8 * run8)) * ch_groups * fields < 2 * 3072) run8 >>= 1;
+        long best = -1;
+        for (int cand = 128; cand >= 8; cand >>= 1) {
+            const long t = (long)((kTilesPerField + 8 * cand - 1) / (8 * cand)) * ch_groups * fields;
+            const long cost = ((t + 2047) / 2048) * (8 * cand + 12);
+            if (best < 0 || cost < best) { best = cost; run8 = cand; }
+        }
     }
     const int runs = (kTilesPerField + 8 * run8 - 1) / (8 * run8);
     const long tasks = (long)runs * ch_groups * fields;
