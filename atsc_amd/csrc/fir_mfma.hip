@@ -370,7 +370,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     typedef typename Out2<FMT>::type out2_t;
     __shared__ __align__(16) float s_taps[4 * kTapCopy];
     // 53.5 KB per block: three blocks = 12 waves per CU (3 per SIMD at <= 168 VGPRs)
+#ifdef ATSC_FUSED_BURST
     __shared__ __align__(16) float s_stage[kMfmaWaves][16 * kStageRow];    // output image of 16 channels at a time
+#else
+    __shared__ __align__(16) float s_stage[kMfmaWaves][32 * kStageRow];    // output image of the tile: 32 channels x 16 samples
+#endif
     __shared__ __align__(16) uint8_t s_ring[kMfmaWaves][32 * kRingRow];
     __shared__ __align__(16) float s_osc[kMfmaWaves][2][256];              // [re | im] of positions i_group .. +255
     const int tid_ = threadIdx.x;
@@ -413,7 +417,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
         b = *reinterpret_cast<const float4*>(pre_src + kPaddedSyms + i);
     };
     float* stage = s_stage[wv];
+#ifdef ATSC_FUSED_BURST
     float* st_w = stage + (r & 15) * kStageRow + 4 * h;                         // + 8*g: outputs 4g+2h, 4g+2h+1 of channel r
+#else
+    float* st_w = stage + r * kStageRow + 4 * h;                                // + 8*g: outputs 4g+2h, 4g+2h+1 of channel r
+#endif
     const float* st_r = stage + (lane >> 3) * kStageRow + 4 * (lane & 7);       // + 8*q rows
 
     // ---- symbol producer: lane = (channel r, half h)
@@ -633,6 +641,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
         for (int u = 0; u < 8; ++u) {
             const int tile = Tg + u;
             const bool tile_ok = tile < kTilesPerField;
+            (void)tile_ok;
             const int i0 = tile * kTile;
             bw[(u + kKSteps - 1) & 7][0] = levels8(*reinterpret_cast<const uint2*>(ring + ((i0 + 112 + 8 * h) & 255)));
             if (u == 7) {
@@ -673,15 +682,42 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             };
             // (one weight buffer: at 3 waves per SIMD the other waves cover the generation latency; a second buffer costs the
             // 16 registers that decide the occupancy)
+            // One quarter of the PREVIOUS tile's image (8 channels x 16 samples = 1 KB) leaves after every second K-step:
+            // four stores spread over the tile instead of a burst of four at its end.  The memory side takes ~90 cycles
+            // per store instruction at the write ceiling (1.54 ms for the 8.4 M of a launch), a burst fills the CU's store
+            // queue and the waves behind it stop at their own stores with the matrix pipe idle.
+            auto out_store = [&](int q, const float4& v, int ptile, bool ok) {
+                const int c = cg * 32 + 8 * q + (lane >> 3);
+                out_t* d = (ok && c < channels) ? iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + ptile * kTile + 2 * (lane & 7)
+                                                : trash + 2 * lane;
+#ifdef ATSC_FUSED_TRASH   // timing experiment: compute floor (every store into the cache-resident trash area)
+                d = trash + 2 * lane;
+#endif
+#ifdef ATSC_FUSED_NOSTORE   // timing experiment: no store is executed (the condition is never true, the compiler cannot know)
+                if (channels < 0)
+#endif
+                *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
+            };
 #ifdef ATSC_FUSED_NOCOMPUTE   // timing experiment: the store stream alone, in this kernel's own structure
             for (int e = 0; e < 4; ++e) acc[e] = (float)bw[(u + e) & 7][0][e];
 #else
+#ifndef ATSC_FUSED_BURST
+            const bool prev_ok = (u > 0 || t8 > 0) && tile - 1 < kTilesPerField;
+            float4 sv;
+#endif
 #pragma unroll
             for (int ks = 0; ks < kKSteps; ++ks) {
                 h8 ahi, alo;
                 weights(ks, ahi, alo);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bw[(u + ks) & 7][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bw[(u + ks) & 7][0], acc, 0, 0, 0);
+#ifndef ATSC_FUSED_BURST
+                if ((ks & 1) == 0) sv = *reinterpret_cast<const float4*>(st_r + 8 * (ks >> 1) * kStageRow);
+                else {
+                    out_store(ks >> 1, sv, tile - 1, prev_ok);
+                    __builtin_amdgcn_sched_barrier(0);    // the scheduler would otherwise sink the stores to the tile's end
+                }
+#endif
             }
 #endif
             if (u == 7) {
@@ -690,10 +726,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                 *reinterpret_cast<float4*>(pre_dst) = pre_re;
                 *reinterpret_cast<float4*>(pre_dst + 256) = pre_im;
             }
-            // C -> LDS image -> whole 128-byte lines, 16 channels at a time (the image is what bounds the LDS per wave)
+            constexpr float inv = 1.0f / kWScale;
+#ifdef ATSC_FUSED_BURST
+            // C -> LDS image -> whole 128-byte lines, 16 channels at a time, all four stores at the tile's end
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                constexpr float inv = 1.0f / kWScale;
                 if ((r >> 4) == half) {
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq)
@@ -701,29 +738,41 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                             make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv);
                 }
                 lds_order();
-                const int cbase = cg * 32 + 16 * half + (lane >> 3);
-                out_t* dst = iq + (size_t)f * kFieldSyms + i0 + 2 * (lane & 7);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float4 v = *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow);
-                    const int c = cbase + 8 * q;
-                    out_t* d = (tile_ok && c < channels) ? dst + (size_t)c * iq_stride : trash + 2 * lane;
-#ifdef ATSC_FUSED_CONTIG   // timing experiment: same bytes as [field][tile][channel][16 samples], 1 KB contiguous per store
-                    d = iq + (((size_t)f * kTilesPerField + min(tile, kTilesPerField - 1)) * channels + min(c, channels - 1)) * 16 + 2 * (lane & 7);
-#endif
-#ifdef ATSC_FUSED_TRASH   // timing experiment: compute floor (every store into the cache-resident trash area)
-                    d = trash + 2 * lane;
-#endif
-#ifdef ATSC_FUSED_NOSTORE   // timing experiment: no store is executed (the condition is never true, the compiler cannot know)
-                    if (channels < 0)
-#endif
-                    *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
-                }
+                for (int q = 0; q < 2; ++q)
+                    out_store(2 * half + q, *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow), tile, tile_ok);
                 lds_order();
             }
+#else
+            // C -> LDS image of the whole tile (its last quarter was read at K-step 6); it leaves during the next tile
+            lds_order();
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                *reinterpret_cast<float4*>(st_w + 8 * gq) =
+                    make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv);
+            lds_order();
+#endif
         }
         lds_order();
     }
+#ifndef ATSC_FUSED_BURST
+    {   // the run's last tile
+        const int ptile = tile0 + 8 * run8 - 1;
+        const int cq = cg * 32 + (lane >> 3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow);
+            const int c = cq + 8 * q;
+            out_t* d = (ptile < kTilesPerField && c < channels)
+                           ? iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + ptile * kTile + 2 * (lane & 7)
+                           : trash + 2 * lane;
+#ifdef ATSC_FUSED_NOSTORE
+            if (channels < 0)
+#endif
+            *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
+        }
+    }
+#endif
 }
 
 template <int FMT>
