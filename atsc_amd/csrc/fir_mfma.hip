@@ -705,10 +705,17 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             const bool prev_ok = (u > 0 || t8 > 0) && tile - 1 < kTilesPerField;
             float4 sv;
 #endif
+#ifdef ATSC_FUSED_HALFGEN   // timing experiment (wrong results): every second K-step reuses the previous step's weights
+            h8 ahi, alo;
+#endif
 #pragma unroll
             for (int ks = 0; ks < kKSteps; ++ks) {
+#ifdef ATSC_FUSED_HALFGEN
+                if ((ks & 1) == 0) weights(ks, ahi, alo);
+#else
                 h8 ahi, alo;
                 weights(ks, ahi, alo);
+#endif
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bw[(u + ks) & 7][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bw[(u + ks) & 7][0], acc, 0, 0, 0);
 #ifndef ATSC_FUSED_BURST
