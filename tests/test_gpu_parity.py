@@ -155,7 +155,7 @@ def test_channel_groups_11_channels(torch_cuda):
 def test_full_size_batch_channel_independence(torch_cuda):
     """BASELINE config 4 per-GPU shard (64 channels x 64 fields) through a size-independent property: channels are
     independent and deterministic, so 64 copies of one stream give 64 bit-identical outputs; their symbols equal that
-    stream encoded alone, whose IQ (the few-channel FFT form of the FIR, the batch runs the matrix-core form) agrees
+    stream encoded alone, whose IQ agrees
     within the tolerance; and channel 0 is checked against the oracle on its first and last fields."""
     torch = torch_cuda
     C_, nf = 64, 64
@@ -565,3 +565,45 @@ def test_fused_form_bit_identical_to_unfused(torch_cuda, C_, nf):
     got_iq = np.concatenate([outs[atsc_amd.FIR_FUSED][b][1][C_ - 1].reshape(-1) for b in range(2)])
     assert np.array_equal(got_sym, want["sym"])
     assert np.abs(got_iq - want["iq"]).max() <= IQ_TOL
+
+
+@pytest.mark.parametrize("C_,nf", [(64, 64), (64, 16), (32, 64)])
+def test_fused_bench_path_full_size(torch_cuda, C_, nf):
+    """The exact path bench.py measures (BASELINE config 4 per-GPU shard: 64 distinct streams x 64 fields, IQ only ->
+    fused kernel with the longest runs, 1024 tiles) and two more sizes that make the launcher pick other run lengths
+    (512 and 256 tiles).  Checked at full size: the fused kernel's symbol tap equals the separate trellis kernel's
+    symbols bit for bit on every channel; its IQ does not depend on whether the tap is taken (bit-identical); it agrees
+    with the FFT form of the separate path within the tolerance everywhere; and the first, a middle and the last channel
+    are checked against the oracle on their first and last fields."""
+    torch = torch_cuda
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77 + C_ + nf)
+    ts = torch.randint(0, 256, (C_, nf * 312, 188), dtype=torch.uint8, device="cuda", generator=g)
+    ts[:, :, 0] = 0x47
+    st = torch.cuda.current_stream().cuda_stream
+    n = nf * FIELD_SYMBOLS
+
+    def run(form, tap):
+        enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+        enc.set_fir_form(form)
+        d_sym = torch.empty(C_ * n, dtype=torch.uint8, device="cuda") if tap else None
+        d_iq = torch.empty(C_ * n, dtype=torch.complex64, device="cuda")
+        enc.encode_batch(ts.data_ptr(), nf, d_sym.data_ptr() if tap else None, d_iq.data_ptr(), st)
+        torch.cuda.synchronize()
+        return d_sym, torch.view_as_real(d_iq).view(C_, 2 * n)
+
+    _, iq_bench = run(atsc_amd.FIR_AUTO, False)          # what bench.py runs
+    sym_f, iq_f = run(atsc_amd.FIR_FUSED, True)
+    assert bool((iq_bench.view(torch.int32) == iq_f.view(torch.int32)).all()), "the symbol tap changes the IQ"
+    del iq_f
+    sym_u, iq_u = run(atsc_amd.FIR_FFT, True)
+    assert bool((sym_f == sym_u).all()), "fused symbol tap differs from k_trellis_map"
+    assert float((iq_bench - iq_u).abs().max()) <= IQ_TOL, "fused and FFT forms disagree"
+    del iq_u, sym_f
+    for c in (0, C_ // 2 + 1, C_ - 1):
+        want = Oracle().process_fields(ts[c].cpu().numpy().reshape(-1), nf, want=("sym", "iq"))
+        assert np.array_equal(sym_u.view(C_, n)[c].cpu().numpy(), want["sym"]), f"channel {c}"
+        got = iq_bench[c].cpu().numpy()
+        for f in (0, nf - 1):
+            sl = slice(2 * f * FIELD_SYMBOLS, 2 * (f + 1) * FIELD_SYMBOLS)
+            assert np.abs(got[sl] - want["iq"][sl]).max() <= IQ_TOL, f"channel {c} field {f}"
