@@ -41,6 +41,7 @@ struct atsc_hip_encoder {
     uint64_t field_index = 0;
     int pending_fields = 0;    // fields of a batch between encode_begin and encode_finish
     int last_fields = 0;       // field count of the last batch (internal symbol buffer is packed with it)
+    bool sym_internal = false; // the last batch wrote its symbols to the internal buffer (no caller buffer, not the fused form)
     int iq_format = ATSC_HIP_IQ_CF32;
     int fir_form = ATSC_HIP_FIR_AUTO;
     void* d_tables = nullptr;
@@ -328,9 +329,11 @@ extern "C" int atsc_hip_encode_finish(atsc_hip_encoder* e, const void* d_carry_x
                              e->iq_format);
         rc = static_cast<int>(hipGetLastError());
         if (rc) return rc;
+        e->sym_internal = false;
     } else {
         rc = run_back(e, static_cast<const uint4*>(d_carry_xor), fields, sym, sym_stride, s);
         if (rc) return rc;
+        e->sym_internal = d_sym == nullptr;
         rc = run_mix_fir(e, sym, sym_stride, d_iq, fields, s);
         if (rc) return rc;
     }
@@ -551,7 +554,9 @@ extern "C" int atsc_hip_stage_buffer(atsc_hip_encoder* e, int stage, void** d_pt
         case ATSC_HIP_STAGE_INTERLEAVE: p = e->buf.il; st = e->buf.il_stride; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_TRELLIS_PAR: p = e->buf.par; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_TRELLIS_SCAN: p = e->buf.cin; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;
-        case ATSC_HIP_STAGE_TRELLIS_MAP: p = e->d_sym; st = (size_t)e->last_fields * kFieldSyms; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_TRELLIS_MAP:
+            if (!e->sym_internal) return ATSC_HIP_ERR_STATE;  // symbols went to the caller's buffer, or (fused form) nowhere
+            p = e->d_sym; st = (size_t)e->last_fields * kFieldSyms; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_MIX_FIR: p = e->d_osc[e->osc_cur]; st = 0; b = sizeof(float2) * kPaddedSyms; break;
         default: return ATSC_HIP_ERR_ARG;
     }

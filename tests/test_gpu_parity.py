@@ -309,6 +309,24 @@ def test_errors(torch_cuda):
     enc2 = atsc_amd.Encoder(channels=2, max_fields=1)
     with pytest.raises(atsc_amd.AtscHipError):
         enc2.process(np.zeros(188, np.uint8), 1, lambda *a: None)  # streaming path is single-channel
+    # the symbol stage tap is only there when the last batch wrote the internal symbol buffer
+    torch = torch_cuda
+    st = torch.cuda.current_stream().cuda_stream
+    d_iq = torch.empty(2 * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+    enc.encode_batch(d_ts.data_ptr(), 2, None, d_iq.data_ptr(), st)
+    p, nbytes, _ = enc.stage_buffer(atsc_amd.STAGE_TRELLIS_MAP)
+    assert p and nbytes == 2 * FIELD_SYMBOLS
+    d_sym = torch.empty(2 * FIELD_SYMBOLS, dtype=torch.uint8, device="cuda")
+    enc.encode_batch(d_ts.data_ptr(), 2, d_sym.data_ptr(), d_iq.data_ptr(), st)
+    with pytest.raises(atsc_amd.AtscHipError):
+        enc.stage_buffer(atsc_amd.STAGE_TRELLIS_MAP)          # symbols went to the caller's buffer
+    enc16 = atsc_amd.Encoder(channels=16, max_fields=1)
+    d_ts16 = torch.zeros(16 * FIELD_TS_BYTES, dtype=torch.uint8, device="cuda")
+    d_iq16 = torch.empty(16 * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+    enc16.encode_batch(d_ts16.data_ptr(), 1, None, d_iq16.data_ptr(), st)
+    with pytest.raises(atsc_amd.AtscHipError):
+        enc16.stage_buffer(atsc_amd.STAGE_TRELLIS_MAP)        # fused form: no symbols anywhere
+    torch.cuda.synchronize()
 
 
 def test_config5_time_split_equals_continuous(torch_cuda):
