@@ -220,8 +220,9 @@ def main():
             "note": f"algorithmic bytes = {fir_bytes_per_sym:.3f} B/symbol ("
                     + ("0.248 B interleaved bytes in" if fused else "1 B symbol in")
                     + f" + {sample_bytes} B {args.iq_format} out, SURVEY 8d); the measured "
-                    "ceiling of this part without any compute is 1.5-1.7 ms for the pure 8.5 GB write stream and 2.08 ms with a "
-                    "1 GB read stream beside it (scripts/ubench/write_bw.hip, mix_bw.hip), i.e. frac <= ~0.6-0.7; "
+                    "ceiling of this part without any compute is 1.54 ms for the 8.5 GB complex64 store stream in this kernel's "
+                    "own order (scripts/ubench/store_pattern.hip) and 2.08 ms with a 1 GB read stream beside it (mix_bw.hip), "
+                    "i.e. frac <= ~0.55-0.7; the kernel without its stores takes 1.55 ms (DESIGN.md, fused kernel section); "
                     "PMC traffic per launch: profiles/",
             "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes) * msym_s * 1e6 / world / 1e9, 1),
         },
