@@ -248,7 +248,7 @@ int resolve_fir_form(const atsc_hip_encoder* e, bool want_symbols = false) {
     const int form = form_env ? form_env : e->fir_form;
     if (form != ATSC_HIP_FIR_AUTO) return form;
     // the fused kernel pays off when the symbols need not exist in HBM; with the symbol tap requested the separate
-    // k_trellis_map + FFT form is faster (measured 3.19 vs 3.64 ms per 64 x 64 step)
+    // k_trellis_map + FFT form is still a little faster (measured 3.05 vs 3.15 ms per 64 x 64 step)
     if (e->cfg.channels >= kMfmaMinChannels && !want_symbols) return ATSC_HIP_FIR_FUSED;
     return ATSC_HIP_FIR_FFT;
 }

@@ -585,18 +585,19 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     };
 
     // symbol tap: positions [pos, pos + 128) of the ring -> d_sym, one 128-byte line per channel (8 lanes x 16 B)
+    // (every lane always stores, like the IQ path: pieces that do not exist go to the trash area)
     auto tap = [&](int pos, int pieces) {
-        if (!sym_out || (lane & 7) >= pieces) return;
+        if (!sym_out) return;
         const int pp = pos + 16 * (lane & 7);
-        if (pp >= kFieldSyms) return;
+        const bool live = (lane & 7) < pieces && pp < kFieldSyms;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int c = cg * 32 + 8 * q + (lane >> 3);
             const uint8_t* row = s_ring[wv] + (8 * q + (lane >> 3)) * kRingRow + (pp & 255);
             const uint2 a = *reinterpret_cast<const uint2*>(row), b = *reinterpret_cast<const uint2*>(row + 8);
-            if (c < channels)
-                *reinterpret_cast<uint4*>(sym_out + (size_t)c * sym_stride + (size_t)f * kFieldSyms + pp) =
-                    make_uint4(a.x, a.y, b.x, b.y);
+            uint8_t* d = (live && c < channels) ? sym_out + (size_t)c * sym_stride + (size_t)f * kFieldSyms + pp
+                                                : reinterpret_cast<uint8_t*>(trash) + 16 * lane;
+            *reinterpret_cast<uint4*>(d) = make_uint4(a.x, a.y, b.x, b.y);
         }
     };
 
@@ -607,10 +608,10 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
 #pragma unroll
     for (int ks = 0; ks < kKSteps - 1; ++ks)
         bw[ks][0] = levels8(*reinterpret_cast<const uint2*>(ring + ((P0 + 16 * ks + 8 * h) & 255)));
-    if (run == 0) tap(0, 7);         // [0, 112): the field's first symbols, which no group's tap covers
     lds_order();
     produce_until(P0 + 240 + 16, 0, 0, 0, 0, 0, 0, 0);
     lds_order();
+    if (run == 0) tap(0, 8);         // [0, 128): the field's first symbols, which no group's tap covers
 
     float4 pre_re, pre_im;
     osc_fetch(tile0, pre_re, pre_im);
@@ -636,7 +637,9 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
 #endif
         const bool pre_ok = fs_j < 0;
         __builtin_amdgcn_sched_barrier(0);
-        if (Tg < kTilesPerField) tap(16 * Tg + 112, 8);   // [16Tg + 112, 16Tg + 240): produced, not yet overwritten
+        // [16Tg + 128, 16Tg + 256): produced, not yet overwritten, and whole 128-byte lines of the symbol rows (a tap that
+        // straddles lines writes every line in two halves, 9 us apart: 0.8 ms per launch)
+        if (Tg < kTilesPerField) tap(16 * Tg + 128, 8);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int tile = Tg + u;
