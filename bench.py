@@ -75,8 +75,8 @@ def cpu_baseline(sample_fields=400):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
     ap.add_argument("--fields", type=int, default=64, help="fields per channel per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
