@@ -367,14 +367,11 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
     typename OutSample<FMT>::type* __restrict__ trash, int channels, int fields, int run8, int runs_per_field,
     int ch_groups) {
     typedef typename OutSample<FMT>::type out_t;
-    typedef typename Out2<FMT>::type out2_t;
+    constexpr int kPieceSamples = 16 / (int)sizeof(out_t);      // samples in a lane's 16-byte piece of a line
+    constexpr int kLineTiles = kPieceSamples / 2;               // tiles of 16 samples in a 128-byte line: 1 / 2 / 4
     __shared__ __align__(16) float s_taps[4 * kTapCopy];
-    // 53.5 KB per block: three blocks = 12 waves per CU (3 per SIMD at <= 168 VGPRs)
-#ifdef ATSC_FUSED_BURST
-    __shared__ __align__(16) float s_stage[kMfmaWaves][16 * kStageRow];    // output image of 16 channels at a time
-#else
-    __shared__ __align__(16) float s_stage[kMfmaWaves][32 * kStageRow];    // output image of the tile: 32 channels x 16 samples
-#endif
+    // 62.7 KB per block: two blocks = 8 waves per CU (2 per SIMD, which is also what ~210 VGPRs allow)
+    __shared__ __align__(16) float s_stage[kMfmaWaves][32 * kStageRow];    // one 128-byte output line per channel (+ pad)
     __shared__ __align__(16) uint8_t s_ring[kMfmaWaves][32 * kRingRow];
     __shared__ __align__(16) float s_osc[kMfmaWaves][2][256];              // [re | im] of positions i_group .. +255
     const int tid_ = threadIdx.x;
@@ -417,11 +414,8 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
         b = *reinterpret_cast<const float4*>(pre_src + kPaddedSyms + i);
     };
     float* stage = s_stage[wv];
-#ifdef ATSC_FUSED_BURST
-    float* st_w = stage + (r & 15) * kStageRow + 4 * h;                         // + 8*g: outputs 4g+2h, 4g+2h+1 of channel r
-#else
-    float* st_w = stage + r * kStageRow + 4 * h;                                // + 8*g: outputs 4g+2h, 4g+2h+1 of channel r
-#endif
+    float* st_w0 = stage + r * kStageRow;                                       // this lane's channel row of the line image
+    float* st_w = st_w0 + 4 * h;                                                // complex64: + 8*g: outputs 4g+2h, 4g+2h+1
     const float* st_r = stage + (lane >> 3) * kStageRow + 4 * (lane & 7);       // + 8*q rows
 
     // ---- symbol producer: lane = (channel r, half h)
@@ -685,29 +679,31 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             };
             // (one weight buffer: at 3 waves per SIMD the other waves cover the generation latency; a second buffer costs the
             // 16 registers that decide the occupancy)
-            // One quarter of the PREVIOUS tile's image (8 channels x 16 samples = 1 KB) leaves after every second K-step:
-            // four stores spread over the tile instead of a burst of four at its end.  The memory side takes ~90 cycles
-            // per store instruction at the write ceiling (1.54 ms for the 8.4 M of a launch), a burst fills the CU's store
-            // queue and the waves behind it stop at their own stores with the matrix pipe idle.
-            auto out_store = [&](int q, const float4& v, int ptile, bool ok) {
+            // The LDS image holds one 128-byte line per channel in the OUTPUT format: 16 complex64 samples = this tile, 32
+            // CS16 samples = two tiles, 64 CS8 samples = four (kLineTiles) -- a fixed-point format stored tile by tile writes
+            // every line in halves / quarters, and partial lines are what the memory side is slow at.  One quarter of the
+            // PREVIOUS line (8 channels x 128 B = 1 KB) leaves after every second K-step of the tile that follows it: four
+            // stores spread over a tile instead of a burst at its end (a burst fills the CU's store queue and the waves
+            // behind it stop at their own stores with the matrix pipe idle: 2.30 -> 2.255 ms).
+            auto out_store = [&](int q, const uint4& v, int ltile, bool ok) {
                 const int c = cg * 32 + 8 * q + (lane >> 3);
-                out_t* d = (ok && c < channels) ? iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + ptile * kTile + 2 * (lane & 7)
-                                                : trash + 2 * lane;
+                out_t* d = (ok && c < channels)
+                               ? iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + ltile * kTile + kPieceSamples * (lane & 7)
+                               : reinterpret_cast<out_t*>(reinterpret_cast<uint4*>(trash) + lane);
 #ifdef ATSC_FUSED_TRASH   // timing experiment: compute floor (every store into the cache-resident trash area)
-                d = trash + 2 * lane;
+                d = reinterpret_cast<out_t*>(reinterpret_cast<uint4*>(trash) + lane);
 #endif
 #ifdef ATSC_FUSED_NOSTORE   // timing experiment: no store is executed (the condition is never true, the compiler cannot know)
                 if (channels < 0)
 #endif
-                *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
+                *reinterpret_cast<uint4*>(d) = v;
             };
+            const bool store_tile = (u % kLineTiles) == 0;    // this tile's K loop carries the previous line's stores
 #ifdef ATSC_FUSED_NOCOMPUTE   // timing experiment: the store stream alone, in this kernel's own structure
             for (int e = 0; e < 4; ++e) acc[e] = (float)bw[(u + e) & 7][0][e];
 #else
-#ifndef ATSC_FUSED_BURST
-            const bool prev_ok = (u > 0 || t8 > 0) && tile - 1 < kTilesPerField;
-            float4 sv;
-#endif
+            const bool prev_ok = (u >= kLineTiles || t8 > 0) && tile - kLineTiles < kTilesPerField;
+            uint4 sv;
 #ifdef ATSC_FUSED_HALFGEN   // timing experiment (wrong results): every second K-step reuses the previous step's weights
             h8 ahi, alo;
 #endif
@@ -721,13 +717,13 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
 #endif
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bw[(u + ks) & 7][0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bw[(u + ks) & 7][0], acc, 0, 0, 0);
-#ifndef ATSC_FUSED_BURST
-                if ((ks & 1) == 0) sv = *reinterpret_cast<const float4*>(st_r + 8 * (ks >> 1) * kStageRow);
-                else {
-                    out_store(ks >> 1, sv, tile - 1, prev_ok);
-                    __builtin_amdgcn_sched_barrier(0);    // the scheduler would otherwise sink the stores to the tile's end
+                if (store_tile) {
+                    if ((ks & 1) == 0) sv = *reinterpret_cast<const uint4*>(st_r + 8 * (ks >> 1) * kStageRow);
+                    else {
+                        out_store(ks >> 1, sv, tile - kLineTiles, prev_ok);
+                        __builtin_amdgcn_sched_barrier(0);    // the scheduler would otherwise sink the stores to the tile's end
+                    }
                 }
-#endif
             }
 #endif
             if (u == 7) {
@@ -736,53 +732,44 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                 *reinterpret_cast<float4*>(pre_dst) = pre_re;
                 *reinterpret_cast<float4*>(pre_dst + 256) = pre_im;
             }
+            // C -> this tile's part of the line image (the image's last quarter was read at K-step 6 of a store tile)
             constexpr float inv = 1.0f / kWScale;
-#ifdef ATSC_FUSED_BURST
-            // C -> LDS image -> whole 128-byte lines, 16 channels at a time, all four stores at the tile's end
+            const int ph = u % kLineTiles;
+            lds_order();
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if ((r >> 4) == half) {
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq)
-                        *reinterpret_cast<float4*>(st_w + 8 * gq) =
-                            make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv);
+            for (int gq = 0; gq < 4; ++gq) {
+                // outputs 4gq + 2h and 4gq + 2h + 1 of channel r: two complex samples
+                const v2f_t s0 = {acc[4 * gq] * inv, acc[4 * gq + 1] * inv}, s1 = {acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv};
+                if constexpr (FMT == kIqCf32) {
+                    *reinterpret_cast<float4*>(st_w + 8 * gq) = make_float4(s0.x, s0.y, s1.x, s1.y);
+                } else if constexpr (FMT == kIqCs16) {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<uint32_t*>(st_w0) + 16 * ph + 4 * gq + 2 * h) =
+                        make_uint2(to_out<kIqCs16>(s0), to_out<kIqCs16>(s1));
+                } else {
+                    *(reinterpret_cast<uint32_t*>(st_w0) + 8 * ph + 2 * gq + h) =
+                        (uint32_t)to_out<kIqCs8>(s0) | ((uint32_t)to_out<kIqCs8>(s1) << 16);
                 }
-                lds_order();
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    out_store(2 * half + q, *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow), tile, tile_ok);
-                lds_order();
             }
-#else
-            // C -> LDS image of the whole tile (its last quarter was read at K-step 6); it leaves during the next tile
             lds_order();
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq)
-                *reinterpret_cast<float4*>(st_w + 8 * gq) =
-                    make_float4(acc[4 * gq] * inv, acc[4 * gq + 1] * inv, acc[4 * gq + 2] * inv, acc[4 * gq + 3] * inv);
-            lds_order();
-#endif
         }
         lds_order();
     }
-#ifndef ATSC_FUSED_BURST
-    {   // the run's last tile
-        const int ptile = tile0 + 8 * run8 - 1;
+    {   // the run's last line
+        const int ltile = tile0 + 8 * run8 - kLineTiles;
         const int cq = cg * 32 + (lane >> 3);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(st_r + 8 * q * kStageRow);
+            const uint4 v = *reinterpret_cast<const uint4*>(st_r + 8 * q * kStageRow);
             const int c = cq + 8 * q;
-            out_t* d = (ptile < kTilesPerField && c < channels)
-                           ? iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + ptile * kTile + 2 * (lane & 7)
-                           : trash + 2 * lane;
+            out_t* d = (ltile < kTilesPerField && c < channels)
+                           ? iq + (size_t)c * iq_stride + (size_t)f * kFieldSyms + ltile * kTile + kPieceSamples * (lane & 7)
+                           : reinterpret_cast<out_t*>(reinterpret_cast<uint4*>(trash) + lane);
 #ifdef ATSC_FUSED_NOSTORE
             if (channels < 0)
 #endif
-            *reinterpret_cast<out2_t*>(d) = pack2<FMT>(v);
+            *reinterpret_cast<uint4*>(d) = v;
         }
     }
-#endif
 }
 
 template <int FMT>

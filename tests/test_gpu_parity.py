@@ -525,10 +525,11 @@ def test_mfma_form_every_channel_against_oracle(torch_cuda, C_):
         fft.set_fir_form(4)
 
 
-def test_mfma_form_sample_formats(torch_cuda):
-    """CS16 / CS8 out of the matrix-core form == the formula applied to its own CF32 output (33 channels)."""
+@pytest.mark.parametrize("C_,nf", [(33, 1), (64, 3)])
+def test_mfma_form_sample_formats(torch_cuda, C_, nf):
+    """CS16 / CS8 out of the fused matrix-core form (which gathers two / four tiles into whole 128-byte lines before it
+    stores them) == the formula applied to the CF32 output of the unfused matrix-core form, bit for bit."""
     torch = torch_cuda
-    C_, nf = 33, 1
     ts = np.concatenate([ts_mt(900 + c, nf) for c in range(C_)])
     ref = atsc_amd.Encoder(channels=C_, max_fields=nf)
     ref.set_fir_form(atsc_amd.FIR_MFMA)
@@ -537,7 +538,7 @@ def test_mfma_form_sample_formats(torch_cuda):
     n = C_ * nf * FIELD_SYMBOLS
     for fmt, dt, full in ((atsc_amd.IQ_CS16, np.int16, 32767.0), (atsc_amd.IQ_CS8, np.int8, 127.0)):
         enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
-        enc.set_iq_format(fmt)          # AUTO picks the matrix-core form for 33 channels with a fixed-point format
+        enc.set_iq_format(fmt)          # AUTO: fused matrix-core form (>= 16 channels, no symbol tap)
         d_q = torch.full((2 * n * np.dtype(dt).itemsize + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
         enc.encode_batch(d_ts.data_ptr(), nf, None, d_q.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
