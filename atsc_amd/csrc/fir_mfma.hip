@@ -677,8 +677,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
                     alo[j] = ll.x; alo[j + 1] = ll.y;
                 }
             };
-            // (one weight buffer: at 3 waves per SIMD the other waves cover the generation latency; a second buffer costs the
-            // 16 registers that decide the occupancy)
+            // (one weight buffer: the other wave of the SIMD covers the generation latency)
             // The LDS image holds one 128-byte line per channel in the OUTPUT format: 16 complex64 samples = this tile, 32
             // CS16 samples = two tiles, 64 CS8 samples = four (kLineTiles) -- a fixed-point format stored tile by tile writes
             // every line in halves / quarters, and partial lines are what the memory side is slow at.  One quarter of the
