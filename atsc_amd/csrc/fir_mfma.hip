@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves, 2) void k_mix_fir_fused(
             const uint2 a = *reinterpret_cast<const uint2*>(row), b = *reinterpret_cast<const uint2*>(row + 8);
             uint8_t* d = (live && c < channels) ? sym_out + (size_t)c * sym_stride + (size_t)f * kFieldSyms + pp
                                                 : reinterpret_cast<uint8_t*>(trash) + 16 * lane;
-            *reinterpret_cast<uint4*>(d) = make_uint4(a.x, a.y, b.x, b.y);
+            store_line_piece(d, make_uint4(a.x, a.y, b.x, b.y));
         }
     };
 

@@ -118,8 +118,10 @@ def main():
     # Handles with >= 16 channels run the fused kernel (trellis/map/sync + mixer + FIR on the matrix cores): it reads the
     # interleaved bytes (64584 B per field = 0.248 B/symbol) and writes the IQ; the symbols never pass through HBM.
     # Fewer channels: the FFT form behind k_trellis_map, 1 B symbol in + IQ out (9.0 B/symbol for complex64).
-    fused = C_ >= 16 and not args.symbol_tap and os.environ.get("ATSC_FIR_FORM", "fused") == "fused"
+    fused = C_ >= 16 and os.environ.get("ATSC_FIR_FORM", "fused") == "fused"
     fir_bytes_per_sym = (64584.0 / atsc_amd.FIELD_SYMBOLS if fused else 1.0) + sample_bytes
+    if fused and args.symbol_tap:
+        fir_bytes_per_sym += 1.0   # the fused kernel also writes the u8 symbols
     # synthetic 19.39 Mbps TS per channel: PRBS payload behind a 0x47 sync byte, seeded per global channel
     g = torch.Generator(device="cuda")
     g.manual_seed(1234 + rank)
