@@ -626,3 +626,15 @@ def test_fused_bench_path_full_size(torch_cuda, C_, nf):
         for f in (0, nf - 1):
             sl = slice(2 * f * FIELD_SYMBOLS, 2 * (f + 1) * FIELD_SYMBOLS)
             assert np.abs(got[sl] - want["iq"][sl]).max() <= IQ_TOL, f"channel {c} field {f}"
+
+
+def test_fused_randomised_cross_check(torch_cuda):
+    """scripts/fuzz_fused.py, a short run: random channel counts (16..80), field counts and batch sequences; fused kernel ==
+    separate kernels bit for bit (symbols, complex64 IQ), CS16 / CS8 == the formula."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_fused.py"), "8", "5"], capture_output=True,
+                       text=True, timeout=280)
+    assert r.returncode == 0 and "all ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
