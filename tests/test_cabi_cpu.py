@@ -87,3 +87,33 @@ def test_product_never_touches_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", atsc_amd.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out and "atsc_ref" not in out
+
+
+def test_headers_compile_as_plain_c(tmp_path):
+    """The boundary is a C ABI: every public header must compile as C99 (no C++ types, no HIP headers) and a C program
+    must link against the library using only those headers."""
+    import subprocess
+    src = tmp_path / "use_c.c"
+    src.write_text(
+        '#include "atsc_hip.h"\n#include "atsc_ts_ingest.h"\n#include "atsc_hip_resample.h"\n#include <stdio.h>\n'
+        "int main(void) {\n"
+        "    atsc_hip_config cfg = {0, 1, 1, 0};\n"
+        "    atsc_hip_encoder* enc = 0;\n"
+        "    int rc = atsc_hip_create(&cfg, &enc);\n"
+        '    printf("%d %s %u\\n", rc, atsc_hip_error_string(rc), (unsigned)atsc_hip_iq_sample_bytes(ATSC_HIP_IQ_CS16));\n'
+        "    if (rc == 0) atsc_hip_destroy(enc);\n"
+        "    atsc_ts_ingest* in = atsc_ts_ingest_create(0, 0);\n"
+        "    atsc_ts_ingest_destroy(in);\n"
+        "    return 0;\n}\n")
+    exe = tmp_path / "use_c"
+    libdir = os.path.dirname(atsc_amd.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-latsc_hip", f"-Wl,-rpath,{libdir}"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    rc, rest = out.stdout.split(" ", 1)
+    assert rest.strip().endswith(" 4")
+    import torch
+    if not torch.cuda.is_available():
+        assert int(rc) != 0 and "no" in rest.lower()       # no device here: a loud error code, not a fallback
