@@ -247,10 +247,13 @@ int resolve_fir_form(const atsc_hip_encoder* e, bool want_symbols = false) {
     }();
     const int form = form_env ? form_env : e->fir_form;
     if (form != ATSC_HIP_FIR_AUTO) return form;
-    // the fused kernel for every handle with enough channels to fill the matrix tiles, with or without the symbol tap
-    // (64 x 64 step with the tap: 2.78 ms against 3.05 ms for k_trellis_map + the FFT form)
+    // The fused kernel works on groups of 32 channels and costs the same for a partly filled group, the FFT form costs
+    // per channel: fused when at least 80 % of the matrix columns carry a channel (measured, 64 fields, IQ only:
+    // 16 ch 1.08 vs 0.88 ms FFT, 24 ch 1.25 vs 1.22, 32 ch 1.39 vs 1.60, 48 ch 2.40 vs 2.32, 64 ch 2.55 vs 2.95), with or
+    // without the symbol tap (64 x 64 with the tap: 2.78 ms against 3.05 ms for k_trellis_map + the FFT form).
     (void)want_symbols;
-    if (e->cfg.channels >= kMfmaMinChannels) return ATSC_HIP_FIR_FUSED;
+    const int groups = (e->cfg.channels + 31) / 32;
+    if (e->cfg.channels >= kMfmaMinChannels && 5 * e->cfg.channels >= 4 * 32 * groups) return ATSC_HIP_FIR_FUSED;
     return ATSC_HIP_FIR_FFT;
 }
 

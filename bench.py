@@ -115,10 +115,11 @@ def main():
     fmt = {"cf32": atsc_amd.IQ_CF32, "cs16": atsc_amd.IQ_CS16, "cs8": atsc_amd.IQ_CS8}[args.iq_format]
     sample_bytes = {"cf32": 8, "cs16": 4, "cs8": 2}[args.iq_format]
     enc.set_iq_format(fmt)
-    # Handles with >= 16 channels run the fused kernel (trellis/map/sync + mixer + FIR on the matrix cores): it reads the
+    # Handles whose channels fill whole groups of 32 to >= 80 % run the fused kernel (trellis/map/sync + mixer + FIR on the matrix cores): it reads the
     # interleaved bytes (64584 B per field = 0.248 B/symbol) and writes the IQ; the symbols never pass through HBM.
     # Fewer channels: the FFT form behind k_trellis_map, 1 B symbol in + IQ out (9.0 B/symbol for complex64).
-    fused = C_ >= 16 and os.environ.get("ATSC_FIR_FORM", "fused") == "fused"
+    auto_fused = C_ >= 16 and 5 * C_ >= 4 * 32 * ((C_ + 31) // 32)       # the library's AUTO rule (atsc_hip.cpp)
+    fused = {"fused": True, "fft": False, "mfma": False}.get(os.environ.get("ATSC_FIR_FORM", ""), auto_fused)
     fir_bytes_per_sym = (64584.0 / atsc_amd.FIELD_SYMBOLS if fused else 1.0) + sample_bytes
     if fused and args.symbol_tap:
         fir_bytes_per_sym += 1.0   # the fused kernel also writes the u8 symbols

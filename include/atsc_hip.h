@@ -131,7 +131,8 @@ size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown form
  *         regenerated from the interleaved bytes inside the kernel and never pass through HBM.  Only in
  *         atsc_hip_encode_batch / _finish with d_iq != NULL; d_sym is then an optional tap (NULL: no symbols are
  *         written anywhere and atsc_hip_stage_buffer(TRELLIS_MAP) returns ATSC_HIP_ERR_STATE)
- *   AUTO: FUSED for handles with >= 16 channels, FFT otherwise (default)
+ *   AUTO: FUSED when the handle's channels fill at least 80 % of whole groups of 32 (26..32, 52..64, 77..96, ...),
+ *         FFT otherwise (default)
  * No reference counterpart (the reference has one scalar/AVX form, filter.h:16-69). */
 enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2, ATSC_HIP_FIR_FUSED = 3 };
 int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);

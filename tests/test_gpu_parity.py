@@ -320,9 +320,9 @@ def test_errors(torch_cuda):
     enc.encode_batch(d_ts.data_ptr(), 2, d_sym.data_ptr(), d_iq.data_ptr(), st)
     with pytest.raises(atsc_amd.AtscHipError):
         enc.stage_buffer(atsc_amd.STAGE_TRELLIS_MAP)          # symbols went to the caller's buffer
-    enc16 = atsc_amd.Encoder(channels=16, max_fields=1)
-    d_ts16 = torch.zeros(16 * FIELD_TS_BYTES, dtype=torch.uint8, device="cuda")
-    d_iq16 = torch.empty(16 * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+    enc16 = atsc_amd.Encoder(channels=32, max_fields=1)
+    d_ts16 = torch.zeros(32 * FIELD_TS_BYTES, dtype=torch.uint8, device="cuda")
+    d_iq16 = torch.empty(32 * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
     enc16.encode_batch(d_ts16.data_ptr(), 1, None, d_iq16.data_ptr(), st)
     with pytest.raises(atsc_amd.AtscHipError):
         enc16.stage_buffer(atsc_amd.STAGE_TRELLIS_MAP)        # fused form: no symbols anywhere
@@ -538,7 +538,8 @@ def test_mfma_form_sample_formats(torch_cuda, C_, nf):
     n = C_ * nf * FIELD_SYMBOLS
     for fmt, dt, full in ((atsc_amd.IQ_CS16, np.int16, 32767.0), (atsc_amd.IQ_CS8, np.int8, 127.0)):
         enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
-        enc.set_iq_format(fmt)          # AUTO: fused matrix-core form (>= 16 channels, no symbol tap)
+        enc.set_fir_form(atsc_amd.FIR_FUSED)
+        enc.set_iq_format(fmt)
         d_q = torch.full((2 * n * np.dtype(dt).itemsize + 4096,), 0x5A, dtype=torch.uint8, device="cuda")
         enc.encode_batch(d_ts.data_ptr(), nf, None, d_q.data_ptr(), torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
