@@ -35,7 +35,7 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
            "atsc_hip_encode_begin", "atsc_hip_encode_finish",
            "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_export_state", "atsc_hip_import_state",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
-           "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form",
+           "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form",
            "atsc_hip_process_chunked",
            "atsc_hip_error_string", "atsc_hip_version",
            # include/atsc_hip_resample.h
@@ -111,6 +111,7 @@ def load_library():
     L.atsc_hip_get_table.argtypes = [vp, C.c_int, vp, C.c_size_t]
     L.atsc_hip_set_iq_format.argtypes = [vp, C.c_int]
     L.atsc_hip_set_fir_form.argtypes = [vp, C.c_int]
+    L.atsc_hip_get_fir_form.argtypes = [vp]
     L.atsc_hip_iq_sample_bytes.argtypes = [C.c_int]
     L.atsc_hip_iq_sample_bytes.restype = C.c_size_t
     L.atsc_hip_process_chunked.argtypes = [vp, u8p, C.c_uint, C.c_size_t, CHUNK_CB, vp]
@@ -195,6 +196,13 @@ class Encoder:
 
     def set_fir_form(self, form):
         check(self.L.atsc_hip_set_fir_form(self.h, form))
+
+    def fir_form(self):
+        """The FIR form the next batch runs (AUTO resolved)."""
+        form = self.L.atsc_hip_get_fir_form(self.h)
+        if form < 0:
+            check(form)
+        return form
 
     # ---- batched device path
     def encode_batch(self, d_ts, fields, d_sym=None, d_iq=None, stream=None):

@@ -46,12 +46,18 @@ struct atsc_hip_encoder {
     int fir_form = ATSC_HIP_FIR_AUTO;
     void* d_tables = nullptr;
 
-    // streaming path (1 channel)
+    // streaming path (1 channel): two slots so that the upload and the kernels of batch k+1 run while the IQ of batch k
+    // comes back over the host link and its callbacks run
     std::vector<uint8_t> pending;        // bytes of an incomplete field + queued whole fields
-    uint8_t* h_ts_pinned = nullptr;
-    uint8_t* d_ts = nullptr;
-    float2* d_iq = nullptr;
-    float2* h_iq_pinned = nullptr;
+    struct Slot {
+        uint8_t* h_ts = nullptr;         // pinned
+        uint8_t* d_ts = nullptr;
+        uint8_t* d_iq = nullptr;
+        uint8_t* h_iq = nullptr;         // pinned: what the callbacks see
+        hipEvent_t encoded = nullptr;    // kernels of the slot's batch done (compute stream)
+        hipEvent_t copied = nullptr;     // IQ of the slot's batch in h_iq (copy stream)
+    } slot[2];
+    hipStream_t compute_stream = nullptr, copy_stream = nullptr;
 
     // timing: a ring of event sets, one per batch, so a timed region can be read back afterwards
     struct EventSet {
@@ -83,9 +89,15 @@ static int destroy_impl(atsc_hip_encoder* e) {
     hipFree(e->buf.coded); hipFree(e->buf.tail); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
     hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
     hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc_tab); hipFree(e->d_tables);
-    hipFree(e->d_ts); hipFree(e->d_iq);
-    if (e->h_ts_pinned) hipHostFree(e->h_ts_pinned);
-    if (e->h_iq_pinned) hipHostFree(e->h_iq_pinned);
+    for (auto& sl : e->slot) {
+        hipFree(sl.d_ts); hipFree(sl.d_iq);
+        if (sl.h_ts) hipHostFree(sl.h_ts);
+        if (sl.h_iq) hipHostFree(sl.h_iq);
+        if (sl.encoded) hipEventDestroy(sl.encoded);
+        if (sl.copied) hipEventDestroy(sl.copied);
+    }
+    if (e->compute_stream) hipStreamDestroy(e->compute_stream);
+    if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     for (auto& set : e->slots)
         for (auto& ev : set.ev)
             if (ev) hipEventDestroy(ev);
@@ -95,16 +107,39 @@ static int destroy_impl(atsc_hip_encoder* e) {
 
 extern "C" void atsc_hip_destroy(atsc_hip_encoder* enc) { destroy_impl(enc); }
 
+static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out);
+
 extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     if (!cfg || !out || cfg->channels < 1 || cfg->max_fields < 1) return ATSC_HIP_ERR_ARG;
     *out = nullptr;
+    // the table generators and the staging buffer allocate host memory: no C++ exception may cross the C boundary
+    try {
+        return create_impl(cfg, out);
+    } catch (const std::bad_alloc&) {
+        return static_cast<int>(hipErrorOutOfMemory);
+    } catch (...) {
+        return ATSC_HIP_ERR_ARG;
+    }
+}
+
+namespace {
+// frees a half-built handle unless release() was called
+struct HandleGuard {
+    atsc_hip_encoder* e;
+    ~HandleGuard() { if (e) destroy_impl(e); }
+    atsc_hip_encoder* release() { atsc_hip_encoder* r = e; e = nullptr; return r; }
+};
+}  // namespace
+
+static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ATSC_HIP_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return ATSC_HIP_ERR_ARG;
     HIP_TRY(hipSetDevice(cfg->device));
 
     auto* e = new (std::nothrow) atsc_hip_encoder();
-    if (!e) return ATSC_HIP_ERR_ARG;
+    if (!e) return static_cast<int>(hipErrorOutOfMemory);
+    HandleGuard guard{e};   // an exception (std::bad_alloc from the table build) or an early return frees the handle
     e->cfg = *cfg;
     atsc_tables::build(e->tab);
     const size_t C = cfg->channels, F = cfg->max_fields;
@@ -112,7 +147,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
 #define TRY_OR_FREE(expr)                                \
     do {                                                 \
         hipError_t _e = (expr);                          \
-        if (_e != hipSuccess) { destroy_impl(e); return static_cast<int>(_e); } \
+        if (_e != hipSuccess) return static_cast<int>(_e);  \
     } while (0)
 
     // constant tables: one allocation [prbs188 | rs_rows | fsync even | fsync odd]
@@ -174,7 +209,7 @@ extern "C" int atsc_hip_create(const atsc_hip_config* cfg, atsc_hip_encoder** ou
     }
     TRY_OR_FREE(hipDeviceSynchronize());
 #undef TRY_OR_FREE
-    *out = e;
+    *out = guard.release();
     return ATSC_HIP_OK;
 }
 
@@ -235,25 +270,14 @@ int run_back(atsc_hip_encoder* e, const uint4* carry_xor, int fields, uint8_t* d
     return static_cast<int>(hipGetLastError());
 }
 
-// which form of the mixer + FIR this batch runs (include/atsc_hip.h, atsc_hip_set_fir_form)
-int resolve_fir_form(const atsc_hip_encoder* e, bool want_symbols = false) {
-    static const int form_env = [] {
-        const char* v = getenv("ATSC_FIR_FORM");   // A/B runs: overrides the handle's setting
-        if (!v) return 0;
-        if (!strcmp(v, "fft")) return (int)ATSC_HIP_FIR_FFT;
-        if (!strcmp(v, "mfma")) return (int)ATSC_HIP_FIR_MFMA;
-        if (!strcmp(v, "fused")) return (int)ATSC_HIP_FIR_FUSED;
-        return 0;
-    }();
-    const int form = form_env ? form_env : e->fir_form;
-    if (form != ATSC_HIP_FIR_AUTO) return form;
-    // The fused kernel works on groups of 32 channels and costs the same for a partly filled group, the FFT form costs
-    // per channel: fused when at least 80 % of the matrix columns carry a channel (measured, 64 fields, IQ only:
-    // 16 ch 1.08 vs 0.88 ms FFT, 24 ch 1.25 vs 1.22, 32 ch 1.39 vs 1.60, 48 ch 2.40 vs 2.32, 64 ch 2.55 vs 2.95), with or
-    // without the symbol tap (64 x 64 with the tap: 2.78 ms against 3.05 ms for k_trellis_map + the FFT form).
-    (void)want_symbols;
-    const int groups = (e->cfg.channels + 31) / 32;
-    if (e->cfg.channels >= kMfmaMinChannels && 5 * e->cfg.channels >= 4 * 32 * groups) return ATSC_HIP_FIR_FUSED;
+// which form of the mixer + FIR this batch runs (include/atsc_hip.h, atsc_hip_set_fir_form).  A function of the handle's
+// channel count and its fir_form setting only, so every rank of a time-split picks the same one for equal handles.
+int resolve_fir_form(const atsc_hip_encoder* e) {
+    if (e->fir_form != ATSC_HIP_FIR_AUTO) return e->fir_form;
+    // The fused kernel works on groups of kFusedGroup channels and costs the same for a partly filled group, the FFT
+    // form costs per channel: fused when at least 80 % of the matrix columns carry a channel.
+    const int groups = (e->cfg.channels + kFusedGroup - 1) / kFusedGroup;
+    if (5 * e->cfg.channels >= 4 * kFusedGroup * groups) return ATSC_HIP_FIR_FUSED;
     return ATSC_HIP_FIR_FFT;
 }
 
@@ -298,6 +322,7 @@ extern "C" int atsc_hip_encode_begin(atsc_hip_encoder* e, const uint8_t* d_ts, i
     HIP_TRY(hipSetDevice(e->cfg.device));
     auto s = static_cast<hipStream_t>(stream);
     begin_batch_timing(e);
+    e->last_fields = fields;
     rc = run_front(e, d_ts, fields, s);
     if (rc) return rc;
     if (d_span_parity) launch_span_parity(s, e->buf, static_cast<uint4*>(d_span_parity), e->cfg.channels, fields);
@@ -305,21 +330,15 @@ extern "C" int atsc_hip_encode_begin(atsc_hip_encoder* e, const uint8_t* d_ts, i
     return static_cast<int>(hipGetLastError());
 }
 
-extern "C" int atsc_hip_encode_finish(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_sym, void* d_iq,
-                                      void* stream) {
-    if (!e) return ATSC_HIP_ERR_ARG;
-    if (!e->pending_fields) return ATSC_HIP_ERR_STATE;
-    if ((reinterpret_cast<uintptr_t>(d_sym) & 15) || (reinterpret_cast<uintptr_t>(d_iq) & 15) ||
-        (reinterpret_cast<uintptr_t>(d_carry_xor) & 15))
-        return ATSC_HIP_ERR_ARG;
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    auto s = static_cast<hipStream_t>(stream);
-    const int fields = e->pending_fields;
+// After an error the batch is abandoned (pending_fields is cleared, so the handle accepts new batches), but the stream
+// state (interleaver tail, carries, oscillator) may have been advanced part of the way: undefined until
+// atsc_hip_import_state re-seats it (include/atsc_hip.h).
+static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_sym, void* d_iq, hipStream_t s, int fields) {
     uint8_t* sym = d_sym ? d_sym : e->d_sym;
     e->last_fields = fields;
     const size_t sym_stride = (size_t)fields * kFieldSyms;
     int rc;
-    if (d_iq && resolve_fir_form(e, d_sym != nullptr) == ATSC_HIP_FIR_FUSED) {
+    if (d_iq && resolve_fir_form(e) == ATSC_HIP_FIR_FUSED) {
         // carries, then ONE kernel for trellis / map / sync / mixer / FIR: the symbols never pass through HBM; the symbol
         // tap is written only if the caller asked for it (d_sym)
         mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);
@@ -345,8 +364,20 @@ extern "C" int atsc_hip_encode_finish(atsc_hip_encoder* e, const void* d_carry_x
     launch_save_state(s, e->buf, e->cfg.channels, fields);
     mark(e, s, ATSC_HIP_NSTAGES);
     e->field_index += (uint64_t)fields;
-    e->pending_fields = 0;
     return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int atsc_hip_encode_finish(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_sym, void* d_iq,
+                                      void* stream) {
+    if (!e) return ATSC_HIP_ERR_ARG;
+    if (!e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if ((reinterpret_cast<uintptr_t>(d_sym) & 15) || (reinterpret_cast<uintptr_t>(d_iq) & 15) ||
+        (reinterpret_cast<uintptr_t>(d_carry_xor) & 15))
+        return ATSC_HIP_ERR_ARG;   // the batch stays pending: the caller may retry with valid pointers
+    const int fields = e->pending_fields;
+    e->pending_fields = 0;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    return finish_impl(e, d_carry_xor, d_sym, d_iq, static_cast<hipStream_t>(stream), fields);
 }
 
 extern "C" int atsc_hip_encode_batch(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, uint8_t* d_sym, void* d_iq,
@@ -361,6 +392,8 @@ extern "C" int atsc_hip_encode_batch(atsc_hip_encoder* e, const uint8_t* d_ts, i
 extern "C" int atsc_hip_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, int fields, void* d_iq, void* stream) {
     if (!e || !d_sym || !d_iq || fields < 1) return ATSC_HIP_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(d_sym) & 15) || (reinterpret_cast<uintptr_t>(d_iq) & 15)) return ATSC_HIP_ERR_ARG;
+    if (fields > e->cfg.max_fields) return ATSC_HIP_ERR_TOO_LARGE;   // the batch's oscillator table holds max_fields fields
+    if (e->pending_fields) return ATSC_HIP_ERR_STATE;                // would move the oscillator under the pending batch
     HIP_TRY(hipSetDevice(e->cfg.device));
     auto s = static_cast<hipStream_t>(stream);
     begin_batch_timing(e);
@@ -375,23 +408,24 @@ extern "C" int atsc_hip_encode_batch_host(atsc_hip_encoder* e, const uint8_t* h_
                                           void* h_iq) {
     if (!e || !h_ts || fields < 1) return ATSC_HIP_ERR_ARG;
     if (fields > e->cfg.max_fields) return ATSC_HIP_ERR_TOO_LARGE;
+    if (e->pending_fields) return ATSC_HIP_ERR_STATE;
     HIP_TRY(hipSetDevice(e->cfg.device));
     const size_t C = e->cfg.channels;
     const size_t ts_bytes = C * fields * kFieldTs, sym_bytes = C * fields * kFieldSyms;
-    uint8_t* d_ts = nullptr;
-    void* d_iq = nullptr;
-    HIP_TRY(hipMalloc(&d_ts, ts_bytes));
-    int rc = static_cast<int>(hipMemcpy(d_ts, h_ts, ts_bytes, hipMemcpyHostToDevice));
     const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
+    uint8_t* d_ts = nullptr;
+    uint8_t* d_sym = nullptr;   // a symbol tap of its own: the fused form writes symbols nowhere else
+    void* d_iq = nullptr;
+    int rc = static_cast<int>(hipMalloc(&d_ts, ts_bytes));
+    if (!rc) rc = static_cast<int>(hipMemcpy(d_ts, h_ts, ts_bytes, hipMemcpyHostToDevice));
+    if (!rc && h_sym) rc = static_cast<int>(hipMalloc(&d_sym, sym_bytes));
     if (!rc && h_iq) rc = static_cast<int>(hipMalloc(&d_iq, sym_bytes * ss));
-    if (!rc) rc = atsc_hip_encode_batch(e, d_ts, fields, nullptr, d_iq, nullptr);
+    if (!rc) rc = atsc_hip_encode_batch(e, d_ts, fields, d_sym, d_iq, nullptr);
     if (!rc) rc = static_cast<int>(hipDeviceSynchronize());
-    if (!rc && h_sym) {
-        // internal symbol buffer is packed with the batch's own field count
-        rc = static_cast<int>(hipMemcpy(h_sym, e->d_sym, sym_bytes, hipMemcpyDeviceToHost));
-    }
+    if (!rc && h_sym) rc = static_cast<int>(hipMemcpy(h_sym, d_sym, sym_bytes, hipMemcpyDeviceToHost));
     if (!rc && h_iq) rc = static_cast<int>(hipMemcpy(h_iq, d_iq, sym_bytes * ss, hipMemcpyDeviceToHost));
     hipFree(d_ts);
+    hipFree(d_sym);
     hipFree(d_iq);
     return rc;
 }
@@ -412,6 +446,11 @@ extern "C" int atsc_hip_set_fir_form(atsc_hip_encoder* e, int form) {
     return ATSC_HIP_OK;
 }
 
+extern "C" int atsc_hip_get_fir_form(atsc_hip_encoder* e) {
+    if (!e) return ATSC_HIP_ERR_ARG;
+    return resolve_fir_form(e);
+}
+
 extern "C" int atsc_hip_set_iq_format(atsc_hip_encoder* e, int format) {
     if (!e || !atsc_hip_iq_sample_bytes(format)) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
@@ -421,17 +460,51 @@ extern "C" int atsc_hip_set_iq_format(atsc_hip_encoder* e, int format) {
 
 // Streaming path: reference semantics of atsc_encoder_impl::process (atsc.cpp:59-77).  With mtu_samples > 0 every
 // field is handed out in pieces of at most mtu_samples, never spanning a field (util/atsc_encoder.cpp:90-99).
+//
+// A call that completes several batches runs them as a two-slot pipeline: upload + kernels of batch k+1 (compute
+// stream) overlap the download of batch k (copy stream) and its callbacks (this thread).  The callbacks stay
+// synchronous, in field order, on the caller's thread, and every field completed by this call has been delivered
+// when the call returns (atsc.cpp:72-75,89) -- nothing is left in flight between calls.
+namespace {
+
+int streaming_setup(atsc_hip_encoder* e) {
+    const size_t F = e->cfg.max_fields;
+    if (!e->compute_stream) HIP_TRY(hipStreamCreateWithFlags(&e->compute_stream, hipStreamNonBlocking));
+    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    // sized for CF32 (the largest sample format); each piece is retried if an earlier call ran out of memory
+    for (auto& sl : e->slot) {
+        if (!sl.d_ts) HIP_TRY(hipMalloc(&sl.d_ts, F * kFieldTs));
+        if (!sl.d_iq) HIP_TRY(hipMalloc(&sl.d_iq, F * kFieldSyms * sizeof(float2)));
+        if (!sl.h_ts) HIP_TRY(hipHostMalloc(&sl.h_ts, F * kFieldTs, hipHostMallocDefault));
+        if (!sl.h_iq) HIP_TRY(hipHostMalloc(&sl.h_iq, F * kFieldSyms * sizeof(float2), hipHostMallocDefault));
+        if (!sl.encoded) HIP_TRY(hipEventCreateWithFlags(&sl.encoded, hipEventDisableTiming));
+        if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    }
+    return ATSC_HIP_OK;
+}
+
+// Bytes of e->pending that were handed to the GPU are dropped on EVERY way out of process_impl (normal return, HIP
+// error, a callback that throws): those fields have advanced the stream state and must not be encoded again.
+struct ConsumedGuard {
+    atsc_hip_encoder* e;
+    size_t done = 0;
+    ~ConsumedGuard() {
+        if (e->compute_stream) hipStreamSynchronize(e->compute_stream);   // nothing stays in flight between calls
+        if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
+        if (done) e->pending.erase(e->pending.begin(), e->pending.begin() + done);
+    }
+};
+
+}  // namespace
+
 static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb,
                         atsc_hip_chunk_cb chunk_cb, size_t mtu_samples, void* user) {
     if (!e || (!h_pkts && count)) return ATSC_HIP_ERR_ARG;
-    if (e->cfg.channels != 1) return ATSC_HIP_ERR_STATE;
+    if (e->cfg.channels != 1 || e->pending_fields) return ATSC_HIP_ERR_STATE;
     HIP_TRY(hipSetDevice(e->cfg.device));
+    int rc = streaming_setup(e);
+    if (rc) return rc;
     const size_t F = e->cfg.max_fields;
-    // streaming buffers, sized for CF32 (the largest sample format); each is retried if an earlier call ran out of memory
-    if (!e->d_ts) HIP_TRY(hipMalloc(&e->d_ts, F * kFieldTs));
-    if (!e->d_iq) HIP_TRY(hipMalloc(&e->d_iq, F * kFieldSyms * sizeof(float2)));
-    if (!e->h_ts_pinned) HIP_TRY(hipHostMalloc(&e->h_ts_pinned, F * kFieldTs, hipHostMallocDefault));
-    if (!e->h_iq_pinned) HIP_TRY(hipHostMalloc(&e->h_iq_pinned, F * kFieldSyms * sizeof(float2), hipHostMallocDefault));
     const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
     const size_t field_bytes = (size_t)kFieldSyms * ss;
     // copy-before-return contract (atsc.cpp:66); no exception may cross the C boundary
@@ -440,19 +513,37 @@ static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned cou
     } catch (const std::bad_alloc&) {
         return static_cast<int>(hipErrorOutOfMemory);
     }
-    size_t done = 0;
-    while (e->pending.size() - done >= (size_t)kFieldTs) {
-        const int nf = (int)std::min<size_t>((e->pending.size() - done) / kFieldTs, F);
-        std::memcpy(e->h_ts_pinned, e->pending.data() + done, (size_t)nf * kFieldTs);
-        HIP_TRY(hipMemcpyAsync(e->d_ts, e->h_ts_pinned, (size_t)nf * kFieldTs, hipMemcpyHostToDevice, nullptr));
-        int rc = atsc_hip_encode_batch(e, e->d_ts, nf, nullptr, e->d_iq, nullptr);
+    ConsumedGuard consumed{e};
+    int nf_of[2] = {0, 0};
+
+    // upload + kernels + download of the next batch, into slot k & 1; 0 fields if no whole field is left
+    auto submit = [&](unsigned k) -> int {
+        auto& sl = e->slot[k & 1];
+        const int nf = (int)std::min<size_t>((e->pending.size() - consumed.done) / kFieldTs, F);
+        nf_of[k & 1] = nf;
+        if (nf == 0) return ATSC_HIP_OK;
+        std::memcpy(sl.h_ts, e->pending.data() + consumed.done, (size_t)nf * kFieldTs);
+        HIP_TRY(hipMemcpyAsync(sl.d_ts, sl.h_ts, (size_t)nf * kFieldTs, hipMemcpyHostToDevice, e->compute_stream));
+        consumed.done += (size_t)nf * kFieldTs;   // from here on the stream state moves: the bytes count as consumed
+        const int r = atsc_hip_encode_batch(e, sl.d_ts, nf, nullptr, sl.d_iq, e->compute_stream);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(sl.encoded, e->compute_stream));
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream, sl.encoded, 0));
+        HIP_TRY(hipMemcpyAsync(sl.h_iq, sl.d_iq, (size_t)nf * field_bytes, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipEventRecord(sl.copied, e->copy_stream));
+        return ATSC_HIP_OK;
+    };
+
+    rc = submit(0);
+    if (rc) return rc;
+    for (unsigned k = 0; nf_of[k & 1] > 0; ++k) {
+        // slot (k+1) & 1 is free: its previous batch (k-1) was delivered in the last trip
+        rc = submit(k + 1);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(e->h_iq_pinned, e->d_iq, (size_t)nf * field_bytes, hipMemcpyDeviceToHost, nullptr));
-        HIP_TRY(hipStreamSynchronize(nullptr));
-        done += (size_t)nf * kFieldTs;
-        auto* base = reinterpret_cast<uint8_t*>(e->h_iq_pinned);
-        for (int f = 0; f < nf; ++f) {
-            uint8_t* field = base + (size_t)f * field_bytes;
+        auto& sl = e->slot[k & 1];
+        HIP_TRY(hipEventSynchronize(sl.copied));
+        for (int f = 0; f < nf_of[k & 1]; ++f) {
+            uint8_t* field = sl.h_iq + (size_t)f * field_bytes;
             if (cb) cb(user, field, (unsigned)field_bytes);
             if (chunk_cb) {
                 size_t remaining = kFieldSyms;
@@ -464,7 +555,6 @@ static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned cou
             }
         }
     }
-    e->pending.erase(e->pending.begin(), e->pending.begin() + done);
     return ATSC_HIP_OK;
 }
 
@@ -556,8 +646,9 @@ extern "C" int atsc_hip_stage_buffer(atsc_hip_encoder* e, int stage, void** d_pt
             if (!e->buf.coded) return ATSC_HIP_ERR_STATE;  // handle created without ATSC_HIP_FLAG_TAPS
             p = e->buf.coded; st = e->buf.coded_stride; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_INTERLEAVE: p = e->buf.il; st = e->buf.il_stride; b = st * e->cfg.channels; break;
-        case ATSC_HIP_STAGE_TRELLIS_PAR: p = e->buf.par; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;
-        case ATSC_HIP_STAGE_TRELLIS_SCAN: p = e->buf.cin; st = (size_t)e->cfg.max_fields * kParts * 16; b = st * e->cfg.channels; break;
+        // par / cin are packed with the batch's own field count: [channel][last_fields * 26] x 16 B
+        case ATSC_HIP_STAGE_TRELLIS_PAR: p = e->buf.par; st = (size_t)e->last_fields * kParts * 16; b = st * e->cfg.channels; break;
+        case ATSC_HIP_STAGE_TRELLIS_SCAN: p = e->buf.cin; st = (size_t)e->last_fields * kParts * 16; b = st * e->cfg.channels; break;
         case ATSC_HIP_STAGE_TRELLIS_MAP:
             if (!e->sym_internal) return ATSC_HIP_ERR_STATE;  // symbols went to the caller's buffer, or (fused form) nowhere
             p = e->d_sym; st = (size_t)e->last_fields * kFieldSyms; b = st * e->cfg.channels; break;

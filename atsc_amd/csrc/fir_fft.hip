@@ -27,9 +27,6 @@
 // history and the grid is a flat list of equal tasks.
 #include "kernels.h"
 #include "iq_format.h"
-#ifndef ATSC_ABLATE
-#define ATSC_ABLATE 0
-#endif
 
 #include <cmath>
 #include <cstdlib>
@@ -180,18 +177,9 @@ __device__ __forceinline__ void load_row(v2f (&x)[32], const float4* row) {
     }
 }
 
-#if ATSC_ABLATE & 8
-#define TABREAD(e) make_float4(0.5f, 0.25f, 0.125f, 0.75f)
-#else
 #define TABREAD(e) (e)
-#endif
-#if ATSC_ABLATE & 4
-#define LOADROW(x, row) do { } while (0)
-#define STOREEL(x, k, v0, v1) do { x[k] = v0; x[k + 1] = v1; } while (0)
-#else
 #define LOADROW(x, row) load_row(x, row)
 #define STOREEL(x, k, v0, v1) do { *reinterpret_cast<v2f*>(&xs[(k) * kRowPad + t]) = v0; *reinterpret_cast<v2f*>(&xs[((k) + 1) * kRowPad + t]) = v1; } while (0)
-#endif
 
 
 
@@ -255,18 +243,11 @@ __device__ __forceinline__ void pass2_spectrum(v2f (&x)[32], const float4* hs) {
 template <int FMT>
 __device__ __forceinline__ void pass4_store(v2f (&y)[32], typename OutSample<FMT>::type* dst_lo,
                                             typename OutSample<FMT>::type* dst_hi) {
-#if ATSC_ABLATE & 1
-    fft32<true>(y);
-#pragma unroll
-    for (int n = 0; n < kFftValid / 32; ++n) asm volatile("" ::"v"(y[n]));
-    if (y[0].x == 123.456f) dst_lo[0] = to_out<FMT>(y[1]);
-#else
     fft32<true>(y, [&](int i) {
         dst_lo[32 * i] = to_out<FMT>(y[i]);
         if (i + 16 < kRowsLast) dst_lo[32 * (i + 16)] = to_out<FMT>(y[i + 16]);
         else if (i + 16 < kFftValid / 32) dst_hi[32 * (i + 16)] = to_out<FMT>(y[i + 16]);
     });
-#endif
 }
 
 }  // namespace
@@ -356,14 +337,8 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
         pass1<true>(xb, xs, t, tw);
         // ---- inverse pass 2 and the stores
         const bool b_real = c + 1 < c_hi;
-#if ATSC_ABLATE & 16
-        out_t* da = trash_t;
-        out_t* db = trash_t;
-        (void)b_real;
-#else
         out_t* da = iq_f + (size_t)c * iq_stride;
         out_t* db = b_real ? iq_f + (size_t)(c + 1) * iq_stride : trash_t;
-#endif
         pass4_store<FMT>(xa, da, full_block ? da : trash_t);
         pass4_store<FMT>(xb, db, full_block ? db : trash_t);
     }
@@ -438,16 +413,12 @@ void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, 
                         float2* osc_tab, int channels, int fields, int iq_format) {
     // Channels per task: as many as possible (the oscillator slice of a task is read once and shared by its channels),
     // but at least ~8 rounds of tasks over the 4096 half-wave slots of the chip so that the flat task list balances.
-    static const int cpg_env = [] { const char* e = getenv("ATSC_FIR_CH_PER_TASK"); return e ? atoi(e) : 0; }();
-    int ch_per_group = cpg_env;
-    if (ch_per_group <= 0) {
-        const long per_group = (long)kFftBlocks * fields;           // tasks per channel group
-        const long groups = (8L * 4096 + per_group - 1) / per_group;   // groups wanted
-        ch_per_group = (int)(channels / (groups < 1 ? 1 : groups));
-        ch_per_group &= ~1;                                          // whole pairs
-        if (ch_per_group > 32) ch_per_group = 32;
-        if (ch_per_group < 2) ch_per_group = 2;
-    }
+    const long per_group = (long)kFftBlocks * fields;              // tasks per channel group
+    const long groups = (8L * 4096 + per_group - 1) / per_group;   // groups wanted
+    int ch_per_group = (int)(channels / (groups < 1 ? 1 : groups));
+    ch_per_group &= ~1;                                            // whole pairs
+    if (ch_per_group > 32) ch_per_group = 32;
+    if (ch_per_group < 2) ch_per_group = 2;
     if (ch_per_group > channels) ch_per_group = channels;
     const int ch_groups = (channels + ch_per_group - 1) / ch_per_group;
     const long tasks = (long)kFftBlocks * ch_groups * fields;

@@ -330,8 +330,7 @@ static void launch_nt(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, vo
 
 void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
                          const float* osc_planes, int channels, int fields, int iq_format) {
-    static const int run8_env = [] { const char* e = getenv("ATSC_FIR_MFMA_RUN8"); return e ? atoi(e) : 0; }();
-    const int run8 = run8_env > 0 ? run8_env : 4;   // 32 tiles = 512 outputs per wave task
+    const int run8 = 4;   // 32 tiles = 512 outputs per wave task
     // One 32-channel tile per wave (NT = 1: 158 VGPRs, 3 waves per SIMD).  Two tiles per wave would share the weight
     // generation but need ~320 VGPRs with the prefetch registers: measured 3.1 ms against 2.4 ms.
     // kOscTabSlack complex64 (8 KB) behind the table: 64 lanes x 16 B of don't-care stores land there

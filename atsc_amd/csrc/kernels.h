@@ -84,6 +84,6 @@ hipError_t upload_mfma_tables(const float* taps112);
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                           size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
                           int iq_format);
-constexpr int kMfmaMinChannels = 16;   // below this the 32-wide channel tile of the MFMA form is mostly padding: FFT form
+constexpr int kFusedGroup = 32;   // channels per wave task of the fused kernel: a partly filled group costs as much as a full one
 
 }  // namespace atsc_k

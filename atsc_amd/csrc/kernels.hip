@@ -1,6 +1,6 @@
 // gfx950 (MI355X / CDNA4) kernels of the ATSC 8VSB modulator hot path.
 //
-//   k_rand_rs        randomizer (PRBS XOR) + RS(207,187) parity            reference: randomize.h:43-54, reed_solomon.h:192-242
+//   k_rs_parity      RS(207,187) parity of the randomized packets (PRBS XOR by linearity)   reference: randomize.h:43-54, reed_solomon.h:192-242
 //   k_interleave     52-branch convolutional byte interleaver as an LDS shear   reference: interleaver.h:11-108
 //                    (+ the per-part GF(2) parities of the 12 precoders/trellis encoders: trellis.h:10-51,240-242)
 //   k_trellis_scan   exclusive XOR scan of the parities -> carry entering every part
@@ -15,9 +15,6 @@
 #include "trellis_bits.h"
 
 #include <cstdlib>
-#ifndef ATSC_ABLATE
-#define ATSC_ABLATE 0
-#endif
 
 
 namespace atsc_k {
@@ -367,8 +364,7 @@ __global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ t
 
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                        int channels, int fields) {
-    static const int cpb_env = [] { const char* e = getenv("ATSC_IL_CH_PER_BLOCK"); return e ? atoi(e) : kIlChPerBlock; }();
-    const int cpb = cpb_env < 1 ? 1 : cpb_env;
+    const int cpb = kIlChPerBlock;
     dim3 grid(2 * fields, (channels + cpb - 1) / cpb);
     hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, d_ts, ts_stride, reinterpret_cast<const uint32_t*>(b.parity),
                        b.tail, t.prbs188, b.il, b.il_stride, b.par, channels, fields, cpb);

@@ -281,8 +281,7 @@ static void launch_upsample(atsc_hip_resampler* r, hipStream_t s, const float2* 
 template <int FMT>
 static bool try_upsample(atsc_hip_resampler* r, hipStream_t s, const float2* in, size_t n_in, size_t in_stride, void* out,
                          size_t out_stride) {
-    static const bool off = getenv("ATSC_RESAMPLE_GENERIC") != nullptr;   // A/B switch for the tests
-    if (off || r->M != 1 || r->K != 16 || !r->nyquist || r->q0 != 0) return false;
+    if (r->M != 1 || r->K != 16 || !r->nyquist || r->q0 != 0) return false;
     switch (r->L) {
         case 2: launch_upsample<2, FMT>(r, s, in, n_in, in_stride, out, out_stride); return true;
         case 3: launch_upsample<3, FMT>(r, s, in, n_in, in_stride, out, out_stride); return true;

@@ -1,6 +1,6 @@
 // Constant tables of the 8VSB modulator path (host side).  Each generator cites the reference
-// behaviour it must reproduce bit-for-bit; tests/test_tables.py checks them against the oracle
-// and the golden fixtures.
+// behaviour it must reproduce bit-for-bit; tests/test_cabi_cpu.py::test_tables_match_oracle_and_golden
+// checks them against the oracle and the golden fixtures.
 #include "tables.h"
 
 #include <cmath>
@@ -126,36 +126,35 @@ void build_fsync(Tables& t) {
     }
 }
 
-// ---- RRC taps.  The reference hard-codes them (src/atsc/filter.h:71); they are the classic
-// firdes root-raised-cosine (gain 0.1, 2 samples per "symbol", alpha 0.1152, 111 taps) evaluated
-// in double and rounded to float, plus a zero 112th tap.
+// ---- RRC taps.  The reference hard-codes 111 values + a zero (src/atsc/filter.h:71).  They are a root-raised-cosine
+// pulse sampled at 2 samples per pulse period T (the 8VSB symbol rate is the Nyquist rate of the 5.38 MHz vestigial
+// sideband pulse), roll-off alpha = 0.1152, 111 taps centred on tap 55, DC gain 0.1.  Evaluated here from
+// the textbook closed form of the pulse with u = t/T:
+//
+//     h(u) = [ sin(pi u (1 - a)) + 4 a u cos(pi u (1 + a)) ] / [ pi u (1 - (4 a u)^2) ],     h(0) = 1 - a + 4a/pi
+//
+// (the removable singularity at 4 a u = +-1 is not hit: 4 a u = 0.2304 k never equals 1 for an integer k).  The prototype is
+// rounded to single precision before it is normalised, which is what makes the result agree with the reference's constants
+// to the last bit; tests/test_cabi_cpu.py pins all 112 bit patterns to tests/golden/golden.json["taps_bits"].
+double rrc_pulse(double u, double a) {
+    if (u == 0.0) return 1.0 - a + 4.0 * a / M_PI;
+    const double s = std::sin(M_PI * u * (1.0 - a));
+    const double c = std::cos(M_PI * u * (1.0 + a));
+    const double w = 4.0 * a * u;
+    return (s + w * c) / (M_PI * u * (1.0 - w * w));
+}
+
 void build_taps(Tables& t) {
-    const double alpha = 0.1152, gain = 0.1, spb = 2.0;
-    const int n = 111;
-    float raw[n];
-    double total = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const double xi = i - n / 2;
-        const double x1 = M_PI * xi / spb;
-        double x2 = 4 * alpha * xi / spb;
-        double x3 = x2 * x2 - 1;
-        double num, den;
-        if (std::fabs(x3) >= 0.000001) {
-            num = (i != n / 2) ? std::cos((1 + alpha) * x1) + std::sin((1 - alpha) * x1) / (4 * alpha * xi / spb)
-                               : std::cos((1 + alpha) * x1) + (1 - alpha) * M_PI / (4 * alpha);
-            den = x3 * M_PI;
-        } else {
-            x3 = (1 - alpha) * x1;
-            x2 = (1 + alpha) * x1;
-            num = std::sin(x2) * (1 + alpha) * M_PI - std::cos(x3) * ((1 - alpha) * M_PI * spb) / (4 * alpha * xi) +
-                  std::sin(x3) * spb * spb / (4 * alpha * xi * xi);
-            den = -32 * M_PI * alpha * alpha * xi / spb;
-        }
-        raw[i] = static_cast<float>(4 * alpha * num / den);
-        total += raw[i];
+    constexpr int kLen = 111, kCentre = kLen / 2;
+    constexpr double kRollOff = 0.1152, kDcGain = 0.1, kSamplesPerPeriod = 2.0;
+    float proto[kLen];
+    double dc = 0.0;
+    for (int n = 0; n < kLen; ++n) {
+        proto[n] = static_cast<float>(rrc_pulse((n - kCentre) / kSamplesPerPeriod, kRollOff));
+        dc += proto[n];
     }
-    for (int i = 0; i < n; ++i) t.taps[i] = static_cast<float>(raw[i] * gain / total);
-    t.taps[111] = 0.0f;
+    for (int n = 0; n < kLen; ++n) t.taps[n] = static_cast<float>(proto[n] * kDcGain / dc);
+    t.taps[kLen] = 0.0f;   // 112th tap: pads the filter to a multiple of 16 (filter.h:71 ends in a zero as well)
 }
 
 // ---- oscillator (reference: src/atsc/offset.h:84-106).  NOT an ideal NCO: the phase is computed

@@ -2,11 +2,24 @@
 """bench.py -- throughput of the MI355X 8VSB modulator hot path (BASELINE.json metric).
 
 One "step" = one pass of the whole chain (randomizer -> RS -> interleaver -> trellis/map/sync ->
-mixer+FIR) over one batch of synthetic TS: `--channels` independent channels x `--fields` fields
-per GPU (default 64 x 64 = the per-GPU shard of BASELINE config 4, "512 channels over 8 GPUs").
-Inputs are resident in HBM before the timed region and IQ is written to a resident HBM buffer
-(device sink); nothing crosses PCIe inside the timed region.  Channels shard across ranks with no
-data-path collective (weak scaling): value = symbols of all ranks / max-over-ranks time.
+mixer+FIR) over one batch of synthetic TS.
+
+--mode channels (default, BASELINE config 4): `--channels` independent channels x `--fields` fields per
+  GPU (default 64 x 64 = the per-GPU shard of "512 channels over 8 GPUs").  Channels shard across ranks
+  with no data-path collective (weak scaling): value = symbols of all ranks / max-over-ranks time.
+--mode timesplit (BASELINE config 5): ONE transport stream (or `--channels` of them) cut into contiguous spans of
+  `--fields` fields, one span per rank and step; the ranks hand the trellis state over with one 16-byte-per-channel
+  all-gather (RCCL over xGMI), interleaver history comes from a one-field TS halo.  Before the timed region the
+  spans of the first step are gathered on rank 0 and compared bit for bit (symbols and IQ) with a single-handle
+  encode of the same stream.
+
+Inputs are resident in HBM before the timed region and IQ is written to a resident HBM buffer (device
+sink); nothing crosses PCIe inside the timed region.
+
+Launching: `python bench.py --gpus N` starts N rank processes itself (one per GPU, fresh children, RCCL
+rendezvous on 127.0.0.1); under torchrun (WORLD_SIZE set) it is one of the ranks.  It refuses (non-zero exit)
+to run N ranks on fewer than N devices.  `--cpu-stub` exercises the same launcher / rendezvous / barrier /
+max-over-ranks plumbing over gloo with the GPU step stubbed out (CPU tests only; its line says "stub": true).
 
 Prints ONE JSON line (rank 0).  `roofline` is the mixer+FIR kernel timed with HIP events recorded
 on the launch stream inside the timed region; `cpu_baseline` times the compiled reference
@@ -16,6 +29,8 @@ the host cores of this box, rank 0 at N=1 only, on a bounded sample.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -25,18 +40,36 @@ sys.path.insert(0, ROOT)
 
 SYMBOL_RATE_MSPS = 4500000.0 / 286 * 684 / 1e6  # 10.762238 Msym/s = one real-time channel
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
-FIR_BYTES_PER_SYM = 9.0        # 1 B symbol in + 8 B complex64 out
 CHAIN_BYTES_PER_SYM = 8.225    # whole chain fused minimum (58656 B in + 2083328 B out per field)
+FIELD_SYMBOLS = 313 * 832
+METRIC = "real-time ATSC channels per GPU (Msym/s; 10.76=1 ch) at 1/2/4/8 MI355X"
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+
+
+def host_cores():
+    """CPU cores this process may really use: the affinity mask, capped by a cgroup quota and by the box's CPU share
+    (the pool exports it as OMP_NUM_THREADS; os.cpu_count() there shows the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    why = "affinity mask"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max" and int(quota) // int(period) >= 1 and int(quota) // int(period) < n:
+            n, why = int(quota) // int(period), "cgroup cpu.max"
+    except (OSError, ValueError):
+        pass
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and 0 < int(share) < n:
+        n, why = int(share), "the box's CPU share (OMP_NUM_THREADS)"
+    return n, why
 
 
 def cpu_baseline(sample_fields=400):
     """Reference CPU encoder on this box's host cores (bounded sample: null-packet TS, null sink)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_lib as ol
     use_ref = ol.ref_available()
     kind = "reference" if use_ref else "port"
-    ncores = min(16, os.cpu_count() or 1)
+    ncores, why = host_cores()
     ts = ol.ts_null(sample_fields)
     if not use_ref:
         sample_fields = max(4, sample_fields // 5)  # the scalar port is ~5x slower
@@ -66,19 +99,21 @@ def cpu_baseline(sample_fields=400):
     wall = time.perf_counter() - t0
     multi = ncores * sample_fields * ol.FIELD_SYMS / wall / 1e6
     return {"value": round(multi, 2), "unit": "Msym/s", "cores": ncores, "kind": kind,
+            "cores_from": why, "cpus_visible": os.cpu_count(),
             "single_thread_msym_s": round(single, 2),
             "channels_equiv": round(multi / SYMBOL_RATE_MSPS, 2),
             "sample": f"{sample_fields}-field null-packet TS per thread, in memory, null sink, "
-                      f"{ncores} threads (one encoder each) + 1-thread run"}
+                      f"{ncores} threads = every core this process may use (one encoder each) + 1-thread run"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--channels", type=int, default=64, help="channels per GPU")
-    ap.add_argument("--fields", type=int, default=64, help="fields per channel per step")
+    ap.add_argument("--mode", choices=("channels", "timesplit"), default="channels")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (default 64; 1 in timesplit mode)")
+    ap.add_argument("--fields", type=int, default=64, help="fields per channel per step (per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--symbol-tap", action="store_true",
                     help="also write the u8 symbol tap (the parity check point) inside the timed region; the reference's "
@@ -86,161 +121,411 @@ def main():
     ap.add_argument("--iq-format", choices=("cf32", "cs16", "cs8"), default="cf32",
                     help="IQ sample format of the device sink; cf32 is the reference's payload and the headline "
                          "configuration, cs16/cs8 are the SDR sink formats (SURVEY 8f-3)")
-    args = ap.parse_args()
+    ap.add_argument("--fir-form", choices=("auto", "fft", "mfma", "fused"), default="auto",
+                    help="A/B runs: which kernel computes the mixer + FIR (atsc_hip_set_fir_form)")
+    ap.add_argument("--cpu-stub", action="store_true",
+                    help="CPU tests: launcher + gloo rendezvous + barrier/max-over-ranks plumbing with the GPU step stubbed")
+    args = ap.parse_args(argv)
+    if args.channels is None:
+        args.channels = 1 if args.mode == "timesplit" else 64
+    return args
 
-    # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner, ...) goes to stderr
+
+# ---------------------------------------------------------------------------------------------- launcher
+def launch_ranks(args, argv):
+    """`--gpus N` without a launcher around us: start N fresh rank processes (this process never touches the GPU)."""
+    n = args.gpus
+    if not args.cpu_stub:
+        import torch
+        have = torch.cuda.device_count()   # counting devices does not initialise the GPU runtime
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) are visible: refusing to report a "
+                             f"{n}-GPU number from fewer devices\n")
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ATSC_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 inherits stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = time.time() + 3000
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            code = -9
+        if code != 0 and rc == 0:
+            rc = code if code > 0 else 1
+            for q in procs:          # one rank failed: the others would wait in a collective for ever
+                if q.poll() is None:
+                    q.kill()
+    if rc:
+        sys.stderr.write(f"bench.py: a rank failed (exit {rc}); no result line is valid\n")
+    return rc
+
+
+class Ranks:
+    """RANK / WORLD_SIZE plumbing shared by the GPU path and the CPU stub."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"WORLD_SIZE={self.world} != --gpus {args.gpus}")
+        self.dist = None
+        self.backend = None
+
+    def init(self, backend, device=None):
+        under_launcher = "TORCHELASTIC_RUN_ID" in os.environ or "ATSC_BENCH_SELF_LAUNCHED" in os.environ
+        if self.world > 1 or under_launcher:   # under a launcher the collective path runs even with one rank
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            kw = {"device_id": device} if device is not None else {}
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world, **kw)
+            self.dist, self.backend = dist, backend
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x, device="cpu"):
+        if self.dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device=device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def ranks_seen(self, device="cpu"):
+        """How many ranks, and which device ordinals, the collective backend really connected."""
+        if self.dist is None:
+            return 1, [self.local_rank]
+        import torch
+        mine = torch.tensor([self.local_rank], dtype=torch.int32, device=device)
+        got = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(got, mine)
+        return self.dist.get_world_size(), [int(g.item()) for g in got]
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def emit(json_fd, out):
     sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
+
+def run_stub(args, json_fd):
+    """The rank plumbing with the GPU step replaced by a 1 ms sleep (gloo, CPU)."""
+    rk = Ranks(args)
+    rk.init("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    rk.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    rk.barrier()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0)
+    seen, ordinals = rk.ranks_seen()
+    sym = args.channels * args.fields * FIELD_SYMBOLS * args.steps * rk.world
+    if rk.rank == 0:
+        emit(json_fd, {"metric": METRIC, "value": round(sym / elapsed / 1e6, 2), "unit": "Msym/s", "n_gpus": rk.world,
+                       "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                       "stub": True, "ranks_seen": seen, "rank_devices": ordinals, "backend": "gloo",
+                       "config": {"workload": "CPU stub of the rank plumbing (no GPU work)"}})
+    rk.finish()
+
+
+# ---------------------------------------------------------------------------------------------- GPU ranks
+def load_profile_json(name):
+    try:
+        return json.load(open(os.path.join(PROFILE_DIR, name)))
+    except (OSError, ValueError):
+        return None
+
+
+def make_ts(torch, channels, fields, seed):
+    """Synthetic 19.39 Mbps TS per channel: PRBS payload behind a 0x47 sync byte, every 5th packet null-like."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    ts = torch.randint(0, 256, (channels, fields * 312, 188), dtype=torch.uint8, device="cuda", generator=g)
+    ts[:, :, 0] = 0x47
+    ts[:, ::5, 1:] = 0xFF          # the 'mix' flavour of config 2
+    return ts.contiguous()
+
+
+def run_gpu(args, json_fd):
     import torch
     import atsc_amd
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE={world} != --gpus {args.gpus}")
+    rk = Ranks(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the 8VSB path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:   # under torchrun the RCCL path runs even with one rank
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if rk.local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rk.rank}: no GPU {rk.local_rank} on this node ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(rk.local_rank)
+    rk.init("nccl", torch.device("cuda", rk.local_rank))
+    seen, ordinals = rk.ranks_seen("cuda")
+    if seen != args.gpus or len(set(ordinals)) != args.gpus:
+        raise SystemExit(f"RCCL connected {seen} rank(s) on devices {ordinals}, wanted {args.gpus} distinct GPUs")
 
-    C_, F = args.channels, args.fields
-    enc = atsc_amd.Encoder(channels=C_, max_fields=F, device=local_rank, timing=True)
     fmt = {"cf32": atsc_amd.IQ_CF32, "cs16": atsc_amd.IQ_CS16, "cs8": atsc_amd.IQ_CS8}[args.iq_format]
+    form = {"auto": atsc_amd.FIR_AUTO, "fft": atsc_amd.FIR_FFT, "mfma": atsc_amd.FIR_MFMA,
+            "fused": atsc_amd.FIR_FUSED}[args.fir_form]
     sample_bytes = {"cf32": 8, "cs16": 4, "cs8": 2}[args.iq_format]
-    enc.set_iq_format(fmt)
-    # Handles whose channels fill whole groups of 32 to >= 80 % run the fused kernel (trellis/map/sync + mixer + FIR on the matrix cores): it reads the
-    # interleaved bytes (64584 B per field = 0.248 B/symbol) and writes the IQ; the symbols never pass through HBM.
-    # Fewer channels: the FFT form behind k_trellis_map, 1 B symbol in + IQ out (9.0 B/symbol for complex64).
-    auto_fused = C_ >= 16 and 5 * C_ >= 4 * 32 * ((C_ + 31) // 32)       # the library's AUTO rule (atsc_hip.cpp)
-    fused = {"fused": True, "fft": False, "mfma": False}.get(os.environ.get("ATSC_FIR_FORM", ""), auto_fused)
-    fir_bytes_per_sym = (64584.0 / atsc_amd.FIELD_SYMBOLS if fused else 1.0) + sample_bytes
-    if fused and args.symbol_tap:
-        fir_bytes_per_sym += 1.0   # the fused kernel also writes the u8 symbols
-    # synthetic 19.39 Mbps TS per channel: PRBS payload behind a 0x47 sync byte, seeded per global channel
-    g = torch.Generator(device="cuda")
-    g.manual_seed(1234 + rank)
-    ts = torch.randint(0, 256, (C_, F * 312, 188), dtype=torch.uint8, device="cuda", generator=g)
-    ts[:, :, 0] = 0x47
-    ts[:, ::5, 1:] = 0xFF          # every 5th packet null-like payload (the 'mix' flavour of config 2)
-    ts = ts.contiguous()
-    sym = torch.empty(C_ * F * atsc_amd.FIELD_SYMBOLS, dtype=torch.uint8, device="cuda")
-    iq = torch.empty(C_ * F * atsc_amd.FIELD_SYMBOLS * sample_bytes, dtype=torch.uint8, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    if args.mode == "timesplit":
+        res = bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes)
+    else:
+        res = bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes)
+    res.update({"ranks_seen": seen, "rank_devices": ordinals, "backend": rk.backend or "none"})
+    if rk.rank == 0:
+        if rk.world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the checker must never take the bench down
+                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        emit(json_fd, res)
+    rk.finish()
 
-    def step():
-        enc.encode_batch(ts.data_ptr(), F, sym.data_ptr() if args.symbol_tap else None, iq.data_ptr(), stream)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    enc.timing_reserve(args.steps)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-stage kernel time from the HIP events of the timed region (rank 0's GPU)
+def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world):
+    """Per-stage kernel time from the HIP events of the timed region (this rank's GPU) and the roofline objects."""
     stage_ms = {k: 0.0 for k in atsc_amd.STAGE_NAMES}
     for b in range(args.steps):
         tm = enc.batch_timings(b)
         for k in stage_ms:
             stage_ms[k] += tm[k] / args.steps
-    sym_per_step_gpu = C_ * F * atsc_amd.FIELD_SYMBOLS
-    total_sym = sym_per_step_gpu * args.steps * world
-    msym_s = total_sym / elapsed / 1e6
+    sym_per_step_gpu = C_ * F * FIELD_SYMBOLS
+    # fused: 64584 interleaved bytes per field in (0.248 B/symbol) + IQ out; separate kernels: 1 B symbol in + IQ out
+    fir_bytes_per_sym = (64584.0 / FIELD_SYMBOLS if fused else 1.0) + sample_bytes
+    if fused and args.symbol_tap:
+        fir_bytes_per_sym += 1.0   # the fused kernel also writes the u8 symbols
     fir_s = stage_ms["mix_fir"] / 1e3
-    fir_gbs = fir_bytes_per_sym * sym_per_step_gpu / fir_s / 1e9
+    fir_gbs = fir_bytes_per_sym * sym_per_step_gpu / fir_s / 1e9 if fir_s > 0 else 0.0
 
-    # the other stages against the same roof, with SURVEY 8(d)'s algorithmic bytes per field
-    alg_bytes_field = {"rand_rs": 58656 + 64584, "interleave": 2 * 64584, "trellis_map": 64584 + 260416}
-    stages_roofline = {}
+    # HBM-bound front stages against the HBM roof with SURVEY 8(d)'s algorithmic bytes per field; the RS stage is bound
+    # by LDS table lookups (SURVEY 8d): its utilisation figures come from the committed counter passes
+    alg_bytes_field = {"interleave": 2 * 64584, "trellis_map": 64584 + 260416}
+    stages = {}
     for k, bpf in alg_bytes_field.items():
-        gbs = bpf * C_ * F / (stage_ms[k] / 1e3) / 1e9 if stage_ms[k] > 0 else 0.0
-        stages_roofline[k] = {"algorithmic_bytes_per_launch": bpf * C_ * F, "avg_launch_ms": round(stage_ms[k], 4),
-                              "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+        if stage_ms[k] > 0:
+            gbs = bpf * C_ * F / (stage_ms[k] / 1e3) / 1e9
+            stages[k] = {"bound": "hbm", "algorithmic_bytes_per_launch": bpf * C_ * F, "avg_launch_ms": round(stage_ms[k], 4),
+                         "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+    stages["rand_rs"] = {"bound": "lds", "avg_launch_ms": round(stage_ms["rand_rs"], 4),
+                         "gf256_mul_adds_per_launch": 3740 * 312 * C_ * F}
+    util = load_profile_json("utilisation.json")
+    if util and util.get("workload") == f"{C_} channels x {F} fields":
+        for k, v in util.get("kernels", {}).items():
+            stages.setdefault(k, {}).update(v)
+        stages["_utilisation_source"] = {"file": "profiles/r02/utilisation.json", "commit": util.get("commit")}
 
-    # HBM bytes per launch of the FIR kernel from the committed PMC passes (same workload only)
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01", "traffic.json")))
-        if tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8 and \
-                ("fused" in tj.get("kernel", "")) == fused:
-            traffic = tj["traffic_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
+    traffic, traffic_src = None, None
+    tj = load_profile_json("traffic.json")
+    if tj and tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8 and \
+            ("fused" in tj.get("kernel", "")) == fused:
+        traffic = tj["traffic_bytes_per_launch"]
+        traffic_src = {"file": "profiles/r02/traffic.json", "commit": tj.get("commit"),
+                       "note": "PMC passes of scripts/pmc_traffic.sh on the named commit; not re-measured in this run"}
+    roofline = {
+        "kernel": ("k_mix_fir_fused (precoder/trellis/mapper/sync + pilot/offset mixer + 112-tap RRC FIR as a banded "
+                   "fp16 hi/lo GEMM on the matrix cores, symbols regenerated in LDS)" if fused else
+                   "k_mix_fir_fft (pilot/offset mixer + 112-tap RRC FIR, overlap-save 1024-point FFT form)"),
+        "bound": "hbm",
+        "achieved": round(fir_gbs, 1),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(fir_gbs / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": fir_bytes_per_sym * sym_per_step_gpu,
+        "avg_launch_ms": round(stage_ms["mix_fir"], 4),
+        "note": f"algorithmic bytes = {fir_bytes_per_sym:.3f} B/symbol ("
+                + ("0.248 B interleaved bytes in" if fused else "1 B symbol in")
+                + f" + {sample_bytes} B {args.iq_format} out, SURVEY 8d); peak = the 8 TB/s spec figure (a pure store "
+                "stream of this shape reaches 5.7 TB/s on this part, DESIGN.md)",
+        "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes) * msym_s * 1e6 / world / 1e9, 1),
+    }
+    err = load_profile_json("fused_iq_error.json")
+    if fused and err:
+        roofline["iq_max_abs_error_vs_oracle"] = err
+    return stage_ms, roofline, stages
 
-    out = {
-        "metric": "real-time ATSC channels per GPU (Msym/s; 10.76=1 ch) at 1/2/4/8 MI355X",
-        "value": round(msym_s, 2),
-        "unit": "Msym/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f32",
+
+def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
+    C_, F = args.channels, args.fields
+    enc = atsc_amd.Encoder(channels=C_, max_fields=F, device=rk.local_rank, timing=True)
+    enc.set_iq_format(fmt)
+    enc.set_fir_form(form)
+    fused = enc.fir_form() == atsc_amd.FIR_FUSED
+    ts = make_ts(torch, C_, F, 1234 + rk.rank)     # seeded per rank: every global channel its own stream
+    sym = torch.empty(C_ * F * FIELD_SYMBOLS, dtype=torch.uint8, device="cuda") if args.symbol_tap else None
+    iq = torch.empty(C_ * F * FIELD_SYMBOLS * sample_bytes, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        enc.encode_batch(ts.data_ptr(), F, sym.data_ptr() if args.symbol_tap else None, iq.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    enc.timing_reserve(args.steps)
+    rk.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    rk.barrier()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0, "cuda")
+
+    sym_per_step_gpu = C_ * F * FIELD_SYMBOLS
+    msym_s = sym_per_step_gpu * args.steps * rk.world / elapsed / 1e6
+    stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, rk.world)
+    return {
+        "metric": METRIC, "value": round(msym_s, 2), "unit": "Msym/s", "n_gpus": rk.world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32 (oscillator, mixer products and accumulation in fp32; the FIR's multiplies run on the matrix cores "
+                  "with each fp32 operand split into two fp16 pieces, >= 21 significant bits)" if fused else "f32"),
         "data": "synthetic",
         "config": {"workload": f"{C_} channels x {F} fields per GPU per step (BASELINE config 4 per-GPU shard), "
-                               f"TS resident in HBM, {'symbol tap + ' if args.symbol_tap else ''}{'complex64' if sample_bytes == 8 else args.iq_format} IQ "
-                               "to a device-resident sink",
-                   "channels_per_gpu": C_, "fields_per_step": F, "parallelism": f"channel-sharded x{world}, no collective"},
+                               f"TS resident in HBM, {'symbol tap + ' if args.symbol_tap else ''}"
+                               f"{'complex64' if sample_bytes == 8 else args.iq_format} IQ to a device-resident sink",
+                   "channels_per_gpu": C_, "fields_per_step": F,
+                   "parallelism": f"channel-sharded x{rk.world}, no collective"},
         "realtime_channels": round(msym_s / SYMBOL_RATE_MSPS, 1),
-        "realtime_channels_per_gpu": round(msym_s / SYMBOL_RATE_MSPS / world, 1),
+        "realtime_channels_per_gpu": round(msym_s / SYMBOL_RATE_MSPS / rk.world, 1),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-        "roofline": {
-            "kernel": ("k_mix_fir_fused (precoder/trellis/mapper/sync + pilot/offset mixer + 112-tap RRC FIR as a banded "
-                       "fp16 hi/lo GEMM on the matrix cores, symbols regenerated in LDS)" if fused else
-                       "k_mix_fir_fft (pilot/offset mixer + 112-tap RRC FIR, overlap-save 1024-point FFT form)"),
-            "bound": "hbm",
-            "achieved": round(fir_gbs, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(fir_gbs / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": fir_bytes_per_sym * sym_per_step_gpu,
-            "avg_launch_ms": round(stage_ms["mix_fir"], 4),
-            "note": f"algorithmic bytes = {fir_bytes_per_sym:.3f} B/symbol ("
-                    + ("0.248 B interleaved bytes in" if fused else "1 B symbol in")
-                    + f" + {sample_bytes} B {args.iq_format} out, SURVEY 8d); the measured "
-                    "ceiling of this part without any compute is 1.54 ms for the 8.5 GB complex64 store stream in this kernel's "
-                    "own order (scripts/ubench/store_pattern.hip) and 2.08 ms with a 1 GB read stream beside it (mix_bw.hip), "
-                    "i.e. frac <= ~0.55-0.7; the kernel without its stores takes 1.55 ms (DESIGN.md, fused kernel section); "
-                    "PMC traffic per launch: profiles/",
-            "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes) * msym_s * 1e6 / world / 1e9, 1),
-        },
-        "roofline_other_stages": stages_roofline,
+        "roofline": roofline,
+        "roofline_other_stages": stages,
     }
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline()
-            except Exception as e:  # the checker must never take the bench down
-                out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if dist is not None:
-        dist.destroy_process_group()
+
+
+def bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
+    """BASELINE config 5: `channels` streams, each cut into spans of F fields; in step k rank r encodes the span that
+    starts at field (k * world + r) * F.  A step = prepare (halo field + state import at the span's field index) +
+    encode_begin + the parity all-gather + encode_finish."""
+    from atsc_amd.timesplit import TimeSplitEncoder, exclusive_xor_over_ranks
+    C_, F, W = args.channels, args.fields, rk.world
+    n_span = F * FIELD_SYMBOLS
+    # The stream: every rank generates the same fields [0, W*F) from one seed (only a one-field halo is ever needed
+    # from the neighbour, and it is part of the stream: no transfer).  Steps re-use these fields at later field
+    # indices (the TS content does not matter for timing; field parity and oscillator phase follow the index).
+    ts_all = make_ts(torch, C_, W * F, 4242).view(C_, W * F, 312 * 188)
+    my_ts = ts_all[:, rk.rank * F:(rk.rank + 1) * F].contiguous()
+    halo = ts_all[:, rk.rank * F - 1].contiguous() if rk.rank else None
+    any_halo = halo if halo is not None else ts_all[:, 0].contiguous()   # later steps: every rank starts mid-stream
+    d_sym = torch.empty(C_ * n_span, dtype=torch.uint8, device="cuda")
+    d_iq = torch.empty(C_ * n_span * sample_bytes, dtype=torch.uint8, device="cuda")
+    group = None
+
+    # ---- parity of the first step against ONE handle encoding the whole stream (rank 0 holds the comparison)
+    tse = TimeSplitEncoder(F, device=rk.local_rank, channels=C_, fir_form=form, iq_format=fmt)
+    tse.prepare(rk.rank * F, halo)
+    tse.encode(my_ts, d_sym, d_iq, group)
+    torch.cuda.synchronize()
+    parity = {"checked": False}
+    check_fields = W * F
+    if check_fields * C_ * FIELD_SYMBOLS * (1 + sample_bytes) <= 64e9:
+        if rk.dist is not None:
+            syms = [torch.empty_like(d_sym) for _ in range(W)] if rk.rank == 0 else None
+            iqs = [torch.empty_like(d_iq) for _ in range(W)] if rk.rank == 0 else None
+            rk.dist.gather(d_sym, syms, dst=0)
+            rk.dist.gather(d_iq, iqs, dst=0)
+        else:
+            syms, iqs = [d_sym], [d_iq]
+        if rk.rank == 0:
+            whole = atsc_amd.Encoder(channels=C_, max_fields=W * F, device=rk.local_rank)
+            whole.set_iq_format(fmt)
+            whole.set_fir_form(tse.enc.fir_form())
+            w_sym = torch.empty(C_ * W * n_span, dtype=torch.uint8, device="cuda")
+            w_iq = torch.empty(C_ * W * n_span * sample_bytes, dtype=torch.uint8, device="cuda")
+            whole.encode_batch(ts_all.data_ptr(), W * F, w_sym.data_ptr(), w_iq.data_ptr(),
+                               torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            w_sym = w_sym.view(C_, W, n_span)
+            w_iq = w_iq.view(C_, W, n_span * sample_bytes)
+            sym_bad = sum(int((syms[r].view(C_, n_span) != w_sym[:, r]).sum()) for r in range(W))
+            iq_bad = sum(int((iqs[r].view(C_, n_span * sample_bytes) != w_iq[:, r]).sum()) for r in range(W))
+            parity = {"checked": True, "fields": check_fields, "symbol_mismatches": sym_bad, "iq_byte_mismatches": iq_bad,
+                      "against": "one handle encoding the whole stream on rank 0 (atsc_hip_encode_batch)"}
+            del whole, w_sym, w_iq, syms, iqs
+            if sym_bad or iq_bad:
+                raise SystemExit(f"time-split output differs from the continuous encode: {parity}")
+    rk.barrier()
+
+    # ---- timed region
+    t_exchange = []
+
+    def timed_exchange(par, grp):
+        torch.cuda.synchronize()            # the parity is ready: what follows is the hand-off itself
+        t0 = time.perf_counter()
+        carry = exclusive_xor_over_ranks(par, grp)
+        torch.cuda.synchronize()
+        t_exchange.append(time.perf_counter() - t0)
+        return carry
+
+    def step(k, exchange):
+        first = (k * W + rk.rank) * F
+        tse.prepare(first, any_halo if first else None)
+        tse.encode(my_ts, None if not args.symbol_tap else d_sym, d_iq, group, exchange=exchange)
+
+    for k in range(args.warmup):
+        step(1 + k, exclusive_xor_over_ranks)
+    torch.cuda.synchronize()
+    rk.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(1 + args.warmup + k, timed_exchange)
+    torch.cuda.synchronize()
+    rk.barrier()
+    elapsed = rk.max_over_ranks(time.perf_counter() - t0, "cuda")
+    handoff_us = rk.max_over_ranks(sorted(t_exchange)[len(t_exchange) // 2] * 1e6 if t_exchange else 0.0, "cuda")
+
+    msym_s = C_ * n_span * args.steps * W / elapsed / 1e6
+    return {
+        "metric": METRIC, "value": round(msym_s, 2), "unit": "Msym/s", "n_gpus": W, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 5: {C_} transport stream(s) time-split at field boundaries, {W} span(s) of "
+                               f"{F} fields per step (one per GPU), trellis state handed over by a {16 * C_}-byte all-gather, "
+                               f"interleaver history from a one-field TS halo; {args.iq_format} IQ to a device-resident sink",
+                   "channels": C_, "fields_per_span": F, "parallelism": f"time-split x{W}, one all-gather per step"},
+        "realtime_channels": round(msym_s / SYMBOL_RATE_MSPS, 1),
+        "handoff_latency_us_median": round(handoff_us, 1),
+        "handoff_note": "host-timed: device sync, all-gather of the span parities (RCCL), XOR fold, device sync; max over ranks "
+                        "of each rank's median",
+        "parity": parity,
+        "fir_form": {atsc_amd.FIR_FFT: "fft", atsc_amd.FIR_MFMA: "mfma", atsc_amd.FIR_FUSED: "fused"}[tse.enc.fir_form()],
+    }
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+
+    # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner, ...) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    if args.cpu_stub:
+        run_stub(args, json_fd)
+    else:
+        run_gpu(args, json_fd)
 
 
 if __name__ == "__main__":

@@ -68,7 +68,8 @@ enum {
 
 /* Per-field completion callback of the streaming path.  Replaces the reference's
  * std::function<void(void*,unsigned)> (src/atsc/atsc.h:11): same arguments plus a user pointer.
- * `iq` is library-owned pinned host memory, valid only during the callback (atsc.cpp:89). */
+ * `iq` is library-owned pinned host memory, valid only during the callback (atsc.cpp:89); `bytes` follows the
+ * handle's sample format (atsc_hip_set_iq_format). */
 typedef void (*atsc_hip_field_cb)(void* user, void* iq, unsigned bytes);
 
 /* Replaces atsc::atsc_encoder::create() (src/atsc/atsc.cpp:93-95).  Allocates all device buffers
@@ -80,9 +81,16 @@ void atsc_hip_destroy(atsc_hip_encoder* enc);
 
 /* Replaces atsc::atsc_encoder::process (src/atsc/atsc.cpp:59-77) for a 1-channel handle:
  * `count` contiguous 188-byte TS packets (host memory, copied before return); every completed
- * 312-packet field fires cb(user, iq, 2083328) synchronously, in order, before the call returns.
- * All complete fields available are encoded in GPU batches of up to max_fields.  A trailing partial
- * field stays buffered (no flush API, like the reference). */
+ * 312-packet field fires cb(user, iq, bytes) synchronously, in order, before the call returns; bytes = 260416 x the
+ * handle's sample size: 2083328 for CF32 (the reference's payload), 1041664 for CS16, 520832 for CS8.
+ * All complete fields available are encoded in GPU batches of up to max_fields; when a call completes several
+ * batches, the upload and kernels of batch k+1 overlap the download and callbacks of batch k (two internal slots
+ * and streams) -- nothing stays in flight when the call returns.  A trailing partial field stays buffered (no flush
+ * API, like the reference).
+ * Errors: packets that were handed to the GPU before a failure are dropped from the buffer (they have advanced the
+ * stream state and are not encoded twice); after any error return from a process / encode call the handle's stream
+ * state (interleaver history, trellis state, oscillator) is undefined until atsc_hip_import_state re-seats it.  A
+ * failed atsc_hip_encode_finish abandons the pending batch; the handle accepts new batches afterwards. */
 int atsc_hip_process(atsc_hip_encoder* enc, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb, void* user);
 
 /* Batched multi-channel path behind process_field (src/atsc/atsc.cpp:79-90), device-resident.
@@ -136,6 +144,10 @@ size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown form
  * No reference counterpart (the reference has one scalar/AVX form, filter.h:16-69). */
 enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2, ATSC_HIP_FIR_FUSED = 3 };
 int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);
+/* The form the handle's next batch runs (AUTO resolved: a function of the channel count and the setting only), or a
+ * negative error code.  The forms differ in the last bits of the IQ, so the ranks of a time-split must
+ * all run the same one for the spans to join bit-identically: atsc_amd/timesplit.py compares this value across ranks. */
+int atsc_hip_get_fir_form(atsc_hip_encoder* enc);
 
 /* atsc_hip_process with the radio-side chunking of the reference's transmitter loop (util/atsc_encoder.cpp:84-100:
  * `transfer = min(remaining, MTU)` per writeStream call, chunks never span a field): cb(user, samples, n, format)

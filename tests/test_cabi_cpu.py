@@ -117,3 +117,21 @@ def test_headers_compile_as_plain_c(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert int(rc) != 0 and "no" in rest.lower()       # no device here: a loud error code, not a fallback
+
+
+def test_reference_caller_builds_unchanged_on_the_adapter():
+    """INTEGRATION.md's drop-in claim: the reference's own driver, util/atsc_encoder_null.cpp, compiled UNMODIFIED with
+    `atsc/atsc.h` resolving to atsc_amd/host/atsc_encoder.hpp and linked against libatsc_hip.so (oracle/Makefile,
+    -Wall -Werror).  Build-container only: /root/reference does not travel; nothing of it is copied into the repo."""
+    import subprocess
+    if not os.path.isdir("/root/reference/util"):
+        pytest.skip("reference tree absent")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-B", "_ref/ref_encoder_null_hip"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_encoder_null_hip")
+    out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libatsc_hip.so" in out and "libatsc_ref" not in out
+    import torch
+    if not torch.cuda.is_available():
+        run = subprocess.run([exe, "/dev/null"], capture_output=True, text=True)
+        assert run.returncode != 0 and "no HIP device" in run.stderr     # loud, no CPU fallback

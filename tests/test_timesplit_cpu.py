@@ -33,9 +33,18 @@ def _worker(rank, world, port, pars, expect, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from atsc_amd.timesplit import exclusive_xor_over_ranks
+    import atsc_amd
+    from atsc_amd.timesplit import check_uniform, exclusive_xor_over_ranks
     carry = exclusive_xor_over_ranks(torch.from_numpy(pars[rank]))
-    q.put((rank, bool(np.array_equal(carry.numpy(), expect[rank]))))
+    ok = bool(np.array_equal(carry.numpy(), expect[rank]))
+    # every rank must run the same channel count / FIR form / sample format, or the spans do not join bit-identically
+    check_uniform((1, atsc_amd.FIR_FFT, atsc_amd.IQ_CF32))
+    try:
+        check_uniform((1, atsc_amd.FIR_FFT if rank == 0 else atsc_amd.FIR_FUSED, atsc_amd.IQ_CF32))
+        ok = False
+    except atsc_amd.AtscHipError as e:
+        ok = ok and "disagree" in str(e)
+    q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
