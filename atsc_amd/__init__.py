@@ -33,7 +33,7 @@ STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trell
 # every symbol include/atsc_hip.h declares
 EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_encode_batch",
            "atsc_hip_encode_begin", "atsc_hip_encode_finish",
-           "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_export_state", "atsc_hip_import_state",
+           "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_mix_fir_static", "atsc_hip_export_state", "atsc_hip_import_state",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
            "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form",
            "atsc_hip_process_chunked",
@@ -101,6 +101,7 @@ def load_library():
     L.atsc_hip_encode_finish.argtypes = [vp, vp, u8p, vp, vp]
     L.atsc_hip_encode_batch_host.argtypes = [vp, u8p, C.c_int, u8p, vp]
     L.atsc_hip_mix_fir.argtypes = [vp, u8p, C.c_int, vp, vp]
+    L.atsc_hip_mix_fir_static.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp]
     L.atsc_hip_export_state.argtypes = [vp, C.c_int, C.POINTER(StreamState)]
     L.atsc_hip_import_state.argtypes = [vp, C.c_int, C.POINTER(StreamState)]
     L.atsc_hip_span_parity.argtypes = [vp, C.c_int, u8p]
@@ -262,6 +263,14 @@ class Encoder:
 
     def table(self, which):
         return get_table(which, self.h)
+
+
+STATIC_MAX_FIELDS = 4
+
+
+def mix_fir_static(device, d_sym, channels, fields, field_index, d_iq, iq_format=IQ_CF32, stream=None):
+    """atsc_hip_mix_fir_static: mixer + FIR with no handle and no allocation (include/atsc_hip.h)."""
+    check(load_library().atsc_hip_mix_fir_static(device, d_sym, channels, fields, field_index, d_iq, iq_format, stream))
 
 
 def get_table(which, handle=None):

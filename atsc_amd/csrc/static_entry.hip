@@ -1,0 +1,108 @@
+// atsc_hip_mix_fir_static: the mixer + FIR of atsc_hip_mix_fir (offset.process_field + filter.process_field,
+// reference: src/atsc/atsc.cpp:85-86) for callers that cannot allocate -- code under HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc.  No handle: everything the kernels need beyond the caller's input and output
+// (the oscillator table T_0, the oscillator state entering the batch, and the per-field table T_f of the batch that
+// k_mix_fir_fft reads) lives in ONE file-scope device array, `scratch`, of fixed size; the entry point calls no
+// hipMalloc / hipFree / allocating routine, on the device or on the host, after its one-time set-up per device.
+//
+// Each GPU holds its own copy of `scratch` at its own address: in host code the array's NAME is only a stand-in, so
+// the set-up asks the runtime for the address on the current device (hipGetSymbolAddress) once per device and every use
+// below -- kernel arguments, copies -- goes through that pointer.
+//
+// All calls on one GPU share that GPU's array: calls that overlap on one GPU (two host threads, or two streams
+// without an order between them) race on it.  A call leaves T_(field_index + fields) and the batch table behind; the
+// next call recomputes both from T_0, nothing has to start at zero.
+#include "atsc_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <new>
+
+#include "kernels.h"
+#include "tables.h"
+
+using namespace atsc_k;
+
+namespace {
+
+constexpr int kStaticMaxFields = ATSC_HIP_STATIC_MAX_FIELDS;
+constexpr int kMaxDevices = 64;
+
+// layout of `scratch`, in complex64 entries
+constexpr size_t kOffT0 = 0;                                   // T_0: written once per device at set-up, then read-only
+constexpr size_t kOffStateA = kOffT0 + kPaddedSyms;            // oscillator state entering the batch (T_field_index)
+constexpr size_t kOffStateB = kOffStateA + kPaddedSyms;        // oscillator state leaving the batch
+constexpr size_t kOffTab = kOffStateB + kPaddedSyms;           // T_f of every field of the batch + the slack rows
+constexpr size_t kScratchEntries = kOffTab + (size_t)kStaticMaxFields * kPaddedSyms + kOscTabSlack;
+
+// (3 + 4) x 261248 + 1024 complex64 = 14.6 MB per GPU, held until the process ends
+static __device__ __align__(256) float2 scratch[kScratchEntries];
+
+struct DeviceSetup {
+    float2* ptr = nullptr;   // this device's address of `scratch`
+    float2 scale{};
+    bool ready = false;
+};
+DeviceSetup g_setup[kMaxDevices];
+
+// Once per device, with that device current.  This is the only place that builds host tables and copies them over;
+// it must run outside a graph capture (call the entry point once with fields = 0 to force it).
+int setup_device(int device) {
+    DeviceSetup& d = g_setup[device];
+    if (d.ready) return ATSC_HIP_OK;
+    float2* p = nullptr;
+    hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return static_cast<int>(e);
+    if (!p) return static_cast<int>(hipErrorInvalidSymbol);
+    try {
+        atsc_tables::Tables tab;
+        atsc_tables::build(tab);
+        e = hipMemcpy(p + kOffT0, tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return static_cast<int>(e);
+        e = upload_fft_tables(tab.taps);   // the FFT form's twiddle / spectrum constants of THIS device
+        if (e != hipSuccess) return static_cast<int>(e);
+        d.scale = make_float2(tab.scale[0], tab.scale[1]);
+    } catch (const std::bad_alloc&) {
+        return static_cast<int>(hipErrorOutOfMemory);
+    }
+    d.ptr = p;
+    d.ready = true;
+    return ATSC_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int atsc_hip_mix_fir_static(int device, const uint8_t* d_sym, int channels, int fields, uint64_t field_index,
+                                       void* d_iq, int iq_format, void* stream) {
+    if (device < 0 || device >= kMaxDevices || channels < 1 || fields < 0) return ATSC_HIP_ERR_ARG;
+    if (fields > kStaticMaxFields) return ATSC_HIP_ERR_TOO_LARGE;   // the batch table in `scratch` holds 4 fields
+    if (!atsc_hip_iq_sample_bytes(iq_format)) return ATSC_HIP_ERR_ARG;
+    if (field_index > (uint64_t)1 << 24) return ATSC_HIP_ERR_TOO_LARGE;   // T_f is re-derived by f sequential steps per call
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ATSC_HIP_ERR_NO_DEVICE;
+    if (device >= ndev) return ATSC_HIP_ERR_ARG;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return static_cast<int>(e);
+    const int rc = setup_device(device);
+    if (rc) return rc;
+    if (fields == 0) return ATSC_HIP_OK;   // set-up only
+    if (!d_sym || !d_iq) return ATSC_HIP_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(d_sym) & 15) || (reinterpret_cast<uintptr_t>(d_iq) & 15)) return ATSC_HIP_ERR_ARG;
+
+    const DeviceSetup& d = g_setup[device];
+    auto s = static_cast<hipStream_t>(stream);
+    float2* t0 = d.ptr + kOffT0;
+    float2* state_in = d.ptr + kOffStateA;
+    float2* state_out = d.ptr + kOffStateB;
+    float2* tab = d.ptr + kOffTab;
+    // T_field_index = T_0 (x) scale^field_index by the reference's own sequential fp32 recursion (offset.h:35-41)
+    const float2* osc_in = t0;
+    if (field_index) {
+        launch_osc_advance(s, t0, state_in, d.scale, (unsigned)field_index);
+        osc_in = state_in;
+    }
+    launch_osc_table(s, osc_in, state_out, tab, d.scale, fields, false);
+    launch_mix_fir_fft(s, d_sym, (size_t)fields * kFieldSyms, d_iq, (size_t)fields * kFieldSyms, tab, channels, fields,
+                       iq_format);
+    return static_cast<int>(hipGetLastError());
+}

@@ -163,6 +163,23 @@ int atsc_hip_encode_batch_host(atsc_hip_encoder* enc, const uint8_t* h_ts, int f
  * src/atsc/atsc.cpp:85-86).  Advances the oscillator by `fields`. */
 int atsc_hip_mix_fir(atsc_hip_encoder* enc, const uint8_t* d_sym, int fields, void* d_iq, void* stream);
 
+/* The same mixer + FIR with NO handle and NO allocation.  No counterpart in the reference; it is for callers that cannot
+ * allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Everything the kernels
+ * need beyond d_sym and d_iq (the oscillator table T_0, the oscillator state and the per-field table of the batch) lives
+ * in one fixed device array of the library (14.6 MB per GPU, held until the process ends), so the batch is limited to
+ * ATSC_HIP_STATIC_MAX_FIELDS fields per channel (ATSC_HIP_ERR_TOO_LARGE beyond; any number of channels).
+ *   d_sym : [channels][fields][260416] u8 level indices;  d_iq : [channels][fields][260416] samples in `iq_format`
+ *   field_index : absolute index of the batch's first field (T_f = T_0 (x) scale^f is re-derived from T_0 on every call,
+ *                 by the reference's fp32 recursion, offset.h:35-41); at most 2^24
+ * The first call on a device sets that device up (host tables, two copies to the device): make it outside any graph
+ * capture, e.g. with fields = 0, which does the set-up and nothing else.  After that a call allocates nothing on the
+ * device or the host and is asynchronous on `stream`.  All calls on one GPU share the one array: calls that overlap on a
+ * GPU (different host threads, or streams with no order between them) race; results equal atsc_hip_mix_fir's (FFT form)
+ * bit for bit. */
+#define ATSC_HIP_STATIC_MAX_FIELDS 4
+int atsc_hip_mix_fir_static(int device, const uint8_t* d_sym, int channels, int fields, uint64_t field_index, void* d_iq,
+                            int iq_format, void* stream);
+
 /* Stream state at a field boundary: everything field f+1 needs from the past.
  * Reference counterparts: interleaver next_field contents (atsc.cpp:53-54,82,88), trellis carries
  * (trellis.h:500-502), saved_symbols (atsc.cpp:37, field_sync.h:17,23), field parity
