@@ -172,7 +172,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     e->dtab.fsync = tb + off_fs;
     e->dtab.prbs = tb + off_pr;
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
-    TRY_OR_FREE(upload_mfma_tables(e->tab.taps));
+    TRY_OR_FREE(upload_mm_tables(e->tab.taps));
 
     // per-channel working buffers
     e->buf.max_fields = cfg->max_fields;
