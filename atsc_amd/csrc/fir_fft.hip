@@ -345,7 +345,9 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
 }
 
 // Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41).
-// planes != 0: the same memory as [f][re plane | im plane] of floats (the layout k_mix_fir_mfma reads).
+// planes != 0: the layout of the matrix-core forms (fir_fused.hip): [f][re plane | im plane] of kPaddedSyms dwords, where
+// the dwords 2m, 2m+1 of a plane hold the positions 2m and 2m+1 as fp16 pieces of T * 4096 (kZScale: fp16's normal range):
+// {Th(2m), Th(2m+1)}, {Tl(2m), Tl(2m+1)} with Th = fl16(T * 4096), Tl = fl16(T * 4096 - Th).
 __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in, float2* __restrict__ tab,
                                                    float2* __restrict__ out, float2 sc, int fields, int planes) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -354,8 +356,14 @@ __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in
     float* pl = reinterpret_cast<float*>(tab);
     for (int f = 0; f < fields; ++f) {
         if (planes) {
-            pl[((size_t)f * 2) * kPaddedSyms + i] = t.x;
-            pl[((size_t)f * 2 + 1) * kPaddedSyms + i] = t.y;
+            _Float16* ph = reinterpret_cast<_Float16*>(pl + ((size_t)f * 2) * kPaddedSyms + (i & ~1)) + (i & 1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float v = (c ? t.y : t.x) * 4096.0f;
+                const _Float16 hi = (_Float16)v;
+                ph[(size_t)c * 2 * kPaddedSyms] = hi;                                  // dword 2m of plane c, half i & 1
+                ph[(size_t)c * 2 * kPaddedSyms + 2] = (_Float16)(v - (float)hi);       // dword 2m + 1
+            }
         } else {
             tab[(size_t)f * kPaddedSyms + i] = t;
         }

@@ -55,7 +55,6 @@ constexpr int kWaves = 4;
 constexpr int kRing = 512;                          // positions per channel row of the symbol ring
 constexpr int kRingRow = kRing + 16;                // bytes: 132 dwords = 4 mod 64 -> the 16 rows' b64 reads are conflict-free
 constexpr int kByteTimes = kFieldCoded / 12;           // 5382 byte-times per field, 207 per part
-constexpr int kOscPlane = 36;                       // floats per plane of the oscillator window (32 + 4: re / im on different banks)
 constexpr float kAScale = 65536.0f;                 // taps are scaled into fp16's normal range ...
 constexpr float kZScale = 4096.0f;                  // ... and so are the mixed samples (|z| <= 7.5); 2^-28 undoes both, exactly
 constexpr int kSymShift = 5;                        // ring bytes are v << 5: fp16 (0x6400 | byte) = 1024 + 32 v
@@ -90,31 +89,53 @@ __device__ __forceinline__ uint32_t levels2(uint32_t ring_dword, bool upper) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(h2, pr) * k16 + kb);
 }
 
-// hi = f16(level * t), lo = f16(level * t - hi) for the two fp16 levels of lv and two fp32 oscillator values: the mixer
-// product (offset.h:24-31) and its split in four v_fma_mix instructions (fp16 level and fp32 factor in one fused
-// multiply-add, result rounded to fp16 once).
-__device__ __forceinline__ void mix_split2(uint32_t lv, float ta, float tb, uint32_t& hi, uint32_t& lo) {
-#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of hipcc parses the body too and does not know the gfx950 operands)
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(hi) : "v"(lv), "v"(ta));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(hi) : "v"(lv), "v"(tb));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[1,0,1]" : "=v"(lo) : "v"(lv), "v"(ta), "v"(hi));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[1,0,1] op_sel_hi:[1,0,1]"
-        : "+v"(lo)
-        : "v"(lv), "v"(tb), "v"(hi));
+// The mixer product z = level * T (offset.h:24-31) as two fp16 pieces, for two inputs at once, in three full-rate packed
+// fp16 instructions.  The oscillator arrives already split, T * 4096 = Th + Tl (two fp16 pieces per table entry, made once
+// per position by k_osc_table: the split does not depend on the channel):
+//   hi = fl16(lv * Th)                      v_pk_mul_f16
+//   r  = lv * Th - hi                       v_pk_fma_f16: the rounding error of an fp16 product is an fp16 number, so r is exact
+//   lo = fl16(lv * Tl + r)                  v_pk_fma_f16
+// hi + lo = level * T to 2^-21 relative (the level has 6 significant bits, Th + Tl carries 22 of T's 24).  The first version
+// formed the fp32 product and split it with v_fma_mixlo/hi_f16: 4 instructions per pair that each cost 2.6 x a plain one.
+__device__ __forceinline__ void mix_pair(uint32_t lv, uint32_t th, uint32_t tl, uint32_t& hi, uint32_t& lo) {
+    const h2 l = __builtin_bit_cast(h2, lv), a = __builtin_bit_cast(h2, th), b = __builtin_bit_cast(h2, tl);
+    const h2 p = l * a;
+    const h2 r = __builtin_elementwise_fma(l, a, -p);
+    hi = __builtin_bit_cast(uint32_t, p);
+    lo = __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(l, b, r));
+}
+
+// Two pairs (one ring dword), the two dependency chains interleaved: a packed fp16 instruction that reads the result of the
+// one just before it costs a wait state.
+__device__ __forceinline__ void mix_quad(uint32_t dw, const uint4& t, uint32_t& h0, uint32_t& l0, uint32_t& h1, uint32_t& l1) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (written out: hipcc's scheduler re-orders the C form back into two serial chains)
+    const uint32_t k64 = 0x64646464u, sel01 = 0x04010400u, sel23 = 0x04030402u;
+    const uint32_t k16 = 0x2c002c00u /* 1/16, 1/16 */, kb = 0xd45cd45cu /* -69.75, -69.75 */;
+    uint32_t la, lb;
+    asm("v_perm_b32 %4, %6, %7, %8\n\t"
+        "v_perm_b32 %5, %6, %7, %9\n\t"
+        "v_pk_fma_f16 %4, %4, %10, %11\n\t"
+        "v_pk_fma_f16 %5, %5, %10, %11\n\t"
+        "v_pk_mul_f16 %0, %4, %12\n\t"
+        "v_pk_mul_f16 %2, %5, %14\n\t"
+        "v_pk_fma_f16 %1, %4, %12, %0 neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f16 %3, %5, %14, %2 neg_lo:[0,0,1] neg_hi:[0,0,1]\n\t"
+        "v_pk_fma_f16 %1, %4, %13, %1\n\t"
+        "v_pk_fma_f16 %3, %5, %15, %3"
+        : "=&v"(h0), "=&v"(l0), "=&v"(h1), "=&v"(l1), "=&v"(la), "=&v"(lb)
+        : "v"(k64), "v"(dw), "v"(sel01), "v"(sel23), "v"(k16), "v"(kb), "v"(t.x), "v"(t.y), "v"(t.z), "v"(t.w));
 #else
-    hi = lo = 0;
+    h0 = l0 = h1 = l1 = 0;
 #endif
 }
 
-// One K-step of the B operand for this lane: 8 consecutive inputs of its (channel, component) column
-__device__ __forceinline__ void make_kstep(uint2 sy, float4 t0, float4 t1, h8& bhi, h8& blo) {
-    uint32_t hi[4], lo[4];
-    mix_split2(levels2(sy.x, false), t0.x, t0.y, hi[0], lo[0]);
-    mix_split2(levels2(sy.x, true), t0.z, t0.w, hi[1], lo[1]);
-    mix_split2(levels2(sy.y, false), t1.x, t1.y, hi[2], lo[2]);
-    mix_split2(levels2(sy.y, true), t1.z, t1.w, hi[3], lo[3]);
-    bhi = __builtin_bit_cast(h8, make_uint4(hi[0], hi[1], hi[2], hi[3]));
-    blo = __builtin_bit_cast(h8, make_uint4(lo[0], lo[1], lo[2], lo[3]));
+// One K-step of the B operand for this lane: 8 consecutive inputs of its (channel, component) column.
+// sy: 8 ring bytes; t0, t1: the table entries of the 4 position pairs {Th pair, Tl pair} x 2 each
+__device__ __forceinline__ void make_kstep(uint2 sy, uint4 t0, uint4 t1, uint4& bhi, uint4& blo) {
+    mix_pair(levels2(sy.x, false), t0.x, t0.y, bhi.x, blo.x);
+    mix_pair(levels2(sy.x, true), t0.z, t0.w, bhi.y, blo.y);
+    mix_pair(levels2(sy.y, false), t1.x, t1.y, bhi.z, blo.z);
+    mix_pair(levels2(sy.y, true), t1.z, t1.w, bhi.w, blo.w);
 }
 
 // one component of a sample in the output format (the pair form lives in iq_format.h)
@@ -154,7 +175,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
     typedef typename G::out_t out_t;
     __shared__ __align__(16) uint8_t s_ring[kWaves][kFusedGroup * kRingRow];
     __shared__ __align__(16) uint8_t s_img[kWaves][kFusedGroup * G::kImgRow];
-    __shared__ __align__(16) float s_osc[kWaves][2 * kOscPlane];
+    __shared__ __align__(16) float s_osc[kWaves][2 * kRound * 64];   // [round parity][tile of the round]: [re | im] x 32 newest inputs
 
     // the wave index is made scalar: task, field, tile and every loop bound below are then wave-uniform SGPR values
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
     const int rows_valid = min(kFusedGroup, a.channels - cg * kFusedGroup);   // channel rows of this group that exist
     const int ch = cg * kFusedGroup + min(cl, rows_valid - 1);                // rows past the end repeat the last one; never stored
 
-    // ---- A operand: the Toeplitz tap matrix, constant, in registers
+    // ---- A operand: the Toeplitz tap matrix, constant, in registers (read from LDS per K-step it cost 0.2 ms per launch)
     h8 ahi[kKSteps], alo[kKSteps];
 #pragma unroll
     for (int ks = 0; ks < kKSteps; ++ks) {
@@ -193,6 +214,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         const_cast<float*>(a.planes) + (size_t)f * 2 * kPaddedSyms, 0, 2 * kPaddedSyms * 4, kRsrcFlags);
     const int osc_off = ((lane >> 5) * kPaddedSyms + (lane & 31)) * 4;   // lanes 0..31 the re plane, 32..63 the im plane
     auto osc_fetch = [&](int tile) {   // the 32 newest inputs of `tile`; tiles past the field stay inside the padded table
+#if defined(EXP_NOLOADS) || defined(EXP_NOOSC)
+        return 1.0f + 0.001f * tile;
+#endif
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_osc, osc_off, ((tile < kTiles ? tile : 0) * kTile + 112) * 4, 0));
     };
 
@@ -202,8 +226,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
     uint8_t* img_wr = img + cl * G::kImgRow;                                  // this lane's channel row
     const uint8_t* img_rd = img + st_row * G::kImgRow + 16 * st_piece;        // + q * kRowsPerStore rows
     float* oscw = s_osc[wv];
-    const float* osc_rd = oscw + comp * kOscPlane + 8 * h;                    // + 16 s, + j
-    float* osc_wr = oscw + (lane >> 5) * kOscPlane + (lane & 31);             // lane brings one float of the window
+    const float* osc_rd = oscw + comp * 32 + 8 * h;                           // + 64 u, + 16 s, + j
+    float* osc_wr = oscw + lane;                                              // + 64 u: lane brings one float of a tile's window
 
     // ---- symbol source when not fused: lanes 0..31 bring 16 bytes of a channel row each (row = lane / 2)
     __amdgpu_buffer_rsrc_t rs_sym = rs_osc;
@@ -306,7 +330,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         }
     }
     auto il_fetch = [&](int g, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+#ifdef EXP_ILHOT
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.il) + 3 * (lane + 64 * (g & 7));
+#else
         const uint32_t* src = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(g + pq, kByteTimes - 1);
+#endif
         d0 = src[0]; d1 = src[1]; d2 = src[2];
     };
     // four byte-times: slot pq takes next_g + pq, whose three interleaved dwords are d0..d2
@@ -421,9 +449,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         const uint8_t* sp = a.sym + (size_t)ch * a.sym_stride + (size_t)f * kFieldSyms;
 #pragma unroll
         for (int ks = 0; ks < kKSteps; ++ks) {
-            float4 t0 = *reinterpret_cast<const float4*>(tp + 16 * ks), t1 = *reinterpret_cast<const float4*>(tp + 16 * ks + 4);
-            t0 = make_float4(t0.x * kZScale, t0.y * kZScale, t0.z * kZScale, t0.w * kZScale);
-            t1 = make_float4(t1.x * kZScale, t1.y * kZScale, t1.z * kZScale, t1.w * kZScale);
+            const uint4 t0 = *reinterpret_cast<const uint4*>(tp + 16 * ks), t1 = *reinterpret_cast<const uint4*>(tp + 16 * ks + 4);
             uint2 sy;
             if constexpr (FUSED) {
                 sy = *reinterpret_cast<const uint2*>(ring_rd + ((P0 + 16 * ks) & (kRing - 1)));
@@ -432,10 +458,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                 const uint2 v = *reinterpret_cast<const uint2*>(sp + (pos < kFieldSyms ? pos : pos - kFieldSyms));
                 sy = make_uint2(v.x << kSymShift, v.y << kSymShift);
             }
-            h8 th, tl;
-            make_kstep(sy, t0, t1, th, tl);
-            bhi[ks] = __builtin_bit_cast(uint4, th);
-            blo[ks] = __builtin_bit_cast(uint4, tl);
+            make_kstep(sy, t0, t1, bhi[ks], blo[ks]);
         }
     }
     if constexpr (FUSED) {
@@ -444,14 +467,20 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         lds_order();
     }
     // prefetch FIFOs: entry (t - tile0) % kAhead holds the newest inputs of tile t, for t = tile0 + 1 .. tile0 + kAhead
-    float of[kAhead];
     uint4 ps[kAhead];
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int d = 1; d <= kAhead; ++d) {
-        of[d % kAhead] = osc_fetch(tile0 + d);
-        if constexpr (!FUSED) ps[d % kAhead] = sym_fetch(tile0 + d);
+        for (int d = 1; d <= kAhead; ++d) ps[d % kAhead] = sym_fetch(tile0 + d);
     }
-
+    // The oscillator windows of a whole round sit in LDS, double-buffered by round parity: slot u holds the 32 newest inputs
+    // of tile Tg + u + 1 (what the body of tile Tg + u converts).  The next round's windows are fetched in three groups of
+    // three at tiles 0, 3 and 6 of a round and parked three tiles later, INSIDE the same loop iteration: the wait for them is
+    // then an exact count (the loads of a group plus the stores issued since), and never drains the wave's IQ stores.  (Loads
+    // whose results cross the loop's back edge make hipcc wait for everything at the loop header, and the in-order vmcnt
+    // then stalls the wave until its newest stores have landed: 0.3 ms per launch.)
+    float ofn[3];
+#pragma unroll
+    for (int j = 0; j < kRound; ++j) osc_wr[64 * j] = osc_fetch(tile0 + 1 + j);
     f16v acc_prev;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc_prev[e] = 0.f;
@@ -459,14 +488,19 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
 
     for (int r = 0; r < a.rounds; ++r) {
         const int Tg = tile0 + kRound * r;
+        const int obuf = (r & 1) * kRound * 64;   // this round's half of the oscillator windows
         // FUSED: the interleaved bytes of the next two steps of the producer are fetched NOW and used at the round's end (a
         // load issued at production time would wait, in order, behind every IQ store of the round)
         uint32_t pa0 = 0, pa1 = 0, pa2 = 0, pb0 = 0, pb1 = 0, pb2 = 0;
         const bool pre_ok = fs_j < 0;
+#if !defined(EXP_NOLOADS) && !defined(EXP_NOIL)
         if constexpr (FUSED) {
             il_fetch(next_g, pa0, pa1, pa2);
             il_fetch(next_g + 4, pb0, pb1, pb2);
         }
+#else
+        pa0 = pa1 = pa2 = pb0 = pb1 = pb2 = (uint32_t)(Tg * 0x01030507u);
+#endif
 #pragma unroll
         for (int u = 0; u < kRound; ++u) {
             const int tile = Tg + u;
@@ -482,15 +516,16 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
             const int st_soff = (tile - 1) * G::kRowBytes;
             float y[16];
             uint2 sy[2];
-            float4 tw[4];
+            uint4 tw[4];
             uint4 piece[G::kStores];
             f16v acc = zero16;
             auto side = [&](int i) {
                 if (i == 0) {
-                    // next tile's window (and ring piece); the slot's prefetch is re-issued kAhead tiles ahead
-                    *osc_wr = of[(u + 1) % kAhead] * kZScale;
-                    of[(u + 1) % kAhead] = osc_fetch(tile + 1 + kAhead);
-                    if constexpr (!FUSED) {
+                    if (u % 3 == 0) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) ofn[j] = osc_fetch(Tg + kRound + 1 + u + j);   // three of the next round's windows
+                    }
+                    if constexpr (!FUSED) {   // next tile's ring piece; the slot's prefetch is re-issued kAhead tiles ahead
                         if (lane < 32) sym_park(tile + 1, ps[(u + 1) % kAhead]);
                         ps[(u + 1) % kAhead] = sym_fetch(tile + 1 + kAhead);
                     }
@@ -504,27 +539,44 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
                         sy[s] = *reinterpret_cast<const uint2*>(ring_rd + (((tile + 1) * kTile + 112 + 16 * s) & (kRing - 1)));
-                        tw[2 * s] = *reinterpret_cast<const float4*>(osc_rd + 16 * s);
-                        tw[2 * s + 1] = *reinterpret_cast<const float4*>(osc_rd + 16 * s + 4);
+                        tw[2 * s] = *reinterpret_cast<const uint4*>(osc_rd + obuf + 64 * u + 16 * s);
+                        tw[2 * s + 1] = *reinterpret_cast<const uint4*>(osc_rd + obuf + 64 * u + 16 * s + 4);
                     }
                 }
-                if (i >= 6 && i <= 13) {
-                    // one pair of elements of the next tile's newest K-steps (slots of this tile's K-steps 0 and 1, whose
-                    // MFMAs have issued)
-                    const int c8 = i - 6, s = c8 >> 2, q = c8 & 3;
+                if (i >= 6 && i <= 9) {
+                    // four elements (one ring dword) of the next tile's newest K-steps, into the slots of this tile's K-steps
+                    // 0 and 1, whose MFMAs have issued
+                    const int c4 = i - 6, s = c4 >> 1, d = c4 & 1;
                     const int slot = (2 * u + s) % kKSteps;
-                    const uint32_t dw = (q & 2) ? sy[s].y : sy[s].x;
-                    const float4 t = tw[2 * s + (q >> 1)];
-                    uint32_t hi, lo;
-                    mix_split2(levels2(dw, q & 1), (q & 1) ? t.z : t.x, (q & 1) ? t.w : t.y, hi, lo);
-                    (q == 0 ? bhi[slot].x : q == 1 ? bhi[slot].y : q == 2 ? bhi[slot].z : bhi[slot].w) = hi;
-                    (q == 0 ? blo[slot].x : q == 1 ? blo[slot].y : q == 2 ? blo[slot].z : blo[slot].w) = lo;
+                    const uint32_t dw = d ? sy[s].y : sy[s].x;
+                    const uint4 t = tw[2 * s + d];
+                    uint32_t h0, l0, h1, l1;
+#ifdef EXP_NOGEN
+                    h0 = dw ^ t.x; l0 = dw ^ t.w; h1 = dw ^ t.y; l1 = dw ^ t.z;
+#else
+                    mix_quad(dw, t, h0, l0, h1, l1);
+#endif
+                    if (d == 0) { bhi[slot].x = h0; bhi[slot].y = h1; blo[slot].x = l0; blo[slot].y = l1; }
+                    else        { bhi[slot].z = h0; bhi[slot].w = h1; blo[slot].z = l0; blo[slot].w = l1; }
                 }
+#ifdef EXP_NOOUT
+                if (i == 14) asm volatile("" ::"v"(y[0]), "v"(y[5]), "v"(y[10]), "v"(y[15]));
+                if (a.channels < 0)
+#endif
                 if (i >= 14 && i <= 17) {
                     // C -> line image: register e of lane (n, h) is output row (e & 3) + 8 (e >> 2) + 4 h of column n
 #pragma unroll
                     for (int e = 4 * (i - 14); e < 4 * (i - 13); ++e)
                         put_component<FMT>(img_wr, (e & 3) + 8 * (e >> 2) + 4 * h, comp, y[e]);
+                }
+                if (u % 3 == 2 && i == 26) {
+                    // the group fetched at tile u - 2 goes to the other buffer; at the round's end the producer's interleaved
+                    // bytes are claimed as well, where the wait is still an exact count
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) osc_wr[(kRound * 64 - obuf) + 64 * (u - 2 + j)] = ofn[j];
+                    if constexpr (FUSED) {
+                        if (u == kRound - 1) asm volatile("" ::"v"(pa0), "v"(pa1), "v"(pa2), "v"(pb0), "v"(pb1), "v"(pb2));
+                    }
                 }
                 if (i >= 18 && i < 18 + G::kStores)
                     piece[i - 18] = *reinterpret_cast<const uint4*>(img_rd + (i - 18) * G::kRowsPerStore * G::kImgRow);
@@ -547,11 +599,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                 acc[ks] += (float)bh[0] + (float)bl[1] + (float)ahi[ks][2];
                 side(3 * ks); side(3 * ks + 1); side(3 * ks + 2);
 #else
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bh, acc, 0, 0, 0);
+                const h8 ah = ahi[ks], al = alo[ks];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
                 side(3 * ks);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
                 side(3 * ks + 1);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
                 side(3 * ks + 2);
 #endif
             }
@@ -559,6 +612,9 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         }
         if constexpr (FUSED) {
             // the ring moves on to what the next round reads (nothing is needed behind the run's last tile unless the tap wants it)
+#ifdef EXP_NOPROD
+            if (a.channels < 0)
+#endif
             if (r + 1 < a.rounds || a.sym) {
                 lds_order();
                 const int limit = (Tg + 2 * kRound + 4) * kTile + 16;
