@@ -150,10 +150,11 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
         if (_e != hipSuccess) return static_cast<int>(_e);  \
     } while (0)
 
-    // constant tables: one allocation [prbs188 | rs_rows | fsync even | fsync odd]
+    // constant tables: one allocation [prbs188 | rs_rows | prbs parity | fsync even | fsync odd | prbs | prbs rows]
     const size_t off_prbs = 0, off_rows = align_up(kFieldTs, 256), off_pp = off_rows + atsc_tables::kRsLdsBytes, off_fs = off_pp + kPackets * 32,
                  off_pr = align_up(off_fs + 2 * kSegSyms, 256);
-    const size_t tab_bytes = off_pr + e->tab.prbs.size();
+    const size_t off_prr = align_up(off_pr + e->tab.prbs.size(), 256);
+    const size_t tab_bytes = off_prr + kPackets * 208;
     TRY_OR_FREE(hipMalloc(&e->d_tables, tab_bytes));
     {
         std::vector<uint8_t> h(tab_bytes, 0);
@@ -163,6 +164,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
         std::memcpy(h.data() + off_fs, e->tab.fsync[0].data(), kSegSyms);
         std::memcpy(h.data() + off_fs + kSegSyms, e->tab.fsync[1].data(), kSegSyms);
         std::memcpy(h.data() + off_pr, e->tab.prbs.data(), e->tab.prbs.size());
+        for (int q = 0; q < kPackets; ++q) std::memcpy(h.data() + off_prr + q * 208, e->tab.prbs.data() + q * 187, 187);
         TRY_OR_FREE(hipMemcpy(e->d_tables, h.data(), tab_bytes, hipMemcpyHostToDevice));
     }
     auto* tb = static_cast<uint8_t*>(e->d_tables);
@@ -171,6 +173,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     e->dtab.prbs_parity = reinterpret_cast<const uint4*>(tb + off_pp);
     e->dtab.fsync = tb + off_fs;
     e->dtab.prbs = tb + off_pr;
+    e->dtab.prbs_rows = tb + off_prr;
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
     TRY_OR_FREE(upload_mm_tables(e->tab.taps));
 

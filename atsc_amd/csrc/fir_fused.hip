@@ -687,7 +687,11 @@ void launch_mm(hipStream_t s, FirArgs a) {
     a.runs_per_field = (kTiles + kRound * a.rounds - 1) / (kRound * a.rounds);
     const long tasks = (long)a.runs_per_field * a.ch_groups * a.fields;
     const unsigned grid = (unsigned)((tasks + kWaves - 1) / kWaves);
+#ifdef EXP_ONEBLOCK
+    hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED>), dim3(grid), dim3(64 * kWaves), 24000, s, a);
+#else
     hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+#endif
 }
 
 template <bool FUSED>

@@ -34,6 +34,7 @@ struct DeviceTables {
     const uint4* prbs_parity;  // 312 x 32 B: RS parity of every PRBS row
     const uint8_t* fsync;      // 2 x 832 B (even, odd)
     const uint8_t* prbs;       // 58344 B, plain order (187 per packet)
+    const uint8_t* prbs_rows;  // 312 x 208 B: the PRBS of a packet's 187 data bytes, then zeros over the parity bytes
 };
 
 struct Buffers {

@@ -84,8 +84,12 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_parity(const uint8_t* __restr
         const int s = (int)(P % kPackets);
         const uint4 pa = prbs_parity[2 * s];
         const uint32_t pe = reinterpret_cast<const uint32_t*>(prbs_parity)[8 * s + 4];
-        parity[2 * P] = make_uint4(b0 ^ pa.x, b1 ^ pa.y, b2 ^ pa.z, b3 ^ pa.w);
-        reinterpret_cast<uint32_t*>(parity)[8 * P + 4] = b4 ^ pe;
+        // The record is shifted by three bytes (parity byte j at byte 3 + j): the interleaver keeps a packet's 207 coded
+        // bytes dword-aligned in LDS, where the first parity byte is the top byte of the dword that holds data bytes 184..186
+        const uint32_t p0 = b0 ^ pa.x, p1 = b1 ^ pa.y, p2 = b2 ^ pa.z, p3 = b3 ^ pa.w, p4 = b4 ^ pe;
+        parity[2 * P] = make_uint4(p0 << 24, __builtin_amdgcn_alignbyte(p1, p0, 1), __builtin_amdgcn_alignbyte(p2, p1, 1),
+                                   __builtin_amdgcn_alignbyte(p3, p2, 1));
+        reinterpret_cast<uint2*>(parity)[4 * P + 2] = make_uint2(__builtin_amdgcn_alignbyte(p4, p3, 1), p4 >> 8);
     }
 }
 
@@ -118,7 +122,12 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t* __restrict__ ts
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int i = tid + 256 * k;
-        pv[k] = i < npk * 5 ? par[(i / 5) * 8 + i % 5] : 0u;
+        if (i < npk * 5) {   // dword (i % 5) of the packet's 20 parity bytes: record bytes 3 + 4 (i % 5) ...
+            const uint32_t* rec = par + (i / 5) * 8 + i % 5;
+            pv[k] = __builtin_amdgcn_alignbyte(rec[1], rec[0], 3);
+        } else {
+            pv[k] = 0u;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -187,163 +196,287 @@ __device__ __forceinline__ uint32_t wave_xor_inclusive(uint32_t v, int lane) {
 }
 
 // ======================================================================================= K2 interleaver
-// The coded stream of a channel viewed as rows of 52 bytes is sheared: IL[a][r] = E[a - 4r][r]
-// (IL[M] = E[M - 208*(M mod 52)], B=52, M=4).  A block produces 621 output rows (half a field) from
-// the 42900 coded bytes that start 10608 bytes earlier -- and those are never read from HBM as a coded stream: the
-// block stages the ~208 TS packets that hold them (flat coalesced dword loads, PRBS XOR fused: randomize.h:43-54)
-// plus their 20 parity bytes from k_rs_parity as LDS rows [sync | 187 data | 20 parity] of 53 dwords, i.e. coded
-// byte r of packet q sits at row byte 1 + r.  The four bytes of an output dword lie exactly 207 coded bytes = one
-// packet apart, so one (packet, offset) pair per dword addresses all four.  Packets before the batch (first block of
-// a batch only) come from the channel's saved 10608-byte coded tail.
-// Every thread assembles whole 12-byte groups, so the precoder/trellis parities of the 13 parts of the half-field
-// (reference: trellis.h:240-242) are folded in here (LDS XOR) and no separate pass re-reads the interleaved bytes.
-constexpr int kIlRows = 621;
-constexpr int kIlBytes = kIlRows * 52;               // 32292 output bytes = 2691 groups = 13 parts
-constexpr int kIlSrcBytes = (kIlRows + 204) * 52;    // 42900 coded bytes feed them
-constexpr int kIlGroups = kIlBytes / 12;             // 2691
-constexpr int kIlMaxPk = 210;                        // packets that can overlap 42900 coded bytes
-constexpr int kIlRowDw = 53;
-constexpr int kIlChPerBlock = 4;                     // channels a block walks with its PRBS slice and gather addresses in registers
+// IL[M] = E[M - 208 (M mod 52)]  (B = 52, M = 4), E the channel's continuous RS-coded stream.
+// 52 bytes per output row and 207 bytes per coded packet meet every 10764 bytes = 207 output rows = 52 packets: one CHUNK.
+// Writing an output position of chunk k as (row a < 207, r < 52) and the coded stream in packets,
+//
+//     IL[k][a][r] = packet (52 k + qa - r), byte ta,      with 52 a = 207 qa + ta
+//
+// i.e. an output ROW is a COLUMN of the packet matrix, read upwards over 52 consecutive packets; a -> ta is a bijection of
+// 0..206 (52 * 4 = 1 mod 207), and only the packets of chunks k - 1 and k are touched.  So a block keeps the packets of two
+// chunks in LDS (rows of 53 dwords, a packet's 207 coded bytes dword-aligned: TS bytes 1..187 come in shifted by one byte,
+// XORed with the PRBS, the 20 parity bytes arrive pre-shifted from k_rs_parity) and walks the chunks of whole fields of one
+// channel in order: every TS byte is read once (+ one chunk per block of fields), and the packets of chunk k stay for k + 1.
+// The gather works on dwords: lane = (dword column c, group of four rows rho) reads the SAME dword column of seven
+// consecutive packet rows and forms four output dwords with byte permutes (the four columns of a dword belong to four
+// output rows whose row windows are one packet apart) -- 7 LDS dword reads per 16 output bytes instead of 16 byte reads.
+// The output dwords go to an LDS image of the chunk and leave as 16-byte stores; the pass that stores them also folds in
+// the precoder / trellis parities of the 26 parts of a field (reference: trellis.h:240-242), per dword: a dword of the
+// interleaved stream holds the bytes of four encoders of one byte-time.
+constexpr int kCkPk = 52;                          // packets per chunk
+constexpr int kCkRows = 207;                       // output rows per chunk
+constexpr int kCkBytes = kCkPk * kSegCoded;        // 10764
+constexpr int kCkDw = kCkBytes / 4;                // 2691
+constexpr int kCkTs = kCkPk * kTsBytes;            // 9776 TS bytes per chunk
+constexpr int kCkPerField = kPackets / kCkPk;      // 6
+constexpr int kIlRowDw = 53;                       // LDS row of a packet: 52 dwords + 1 (odd stride)
+constexpr int kIlRing = 2 * kCkPk;                 // 104 packet rows: two chunks, halves alternate
+constexpr int kIlMirror = 6;                       // rows 104..109 repeat rows 0..5: a window of 7 rows never wraps
+constexpr int kIlTasks = kCkPk * 13;               // 676 = (packet, 16-byte piece) when staging = (dword column, 4 rows) when gathering
+constexpr int kIlPieces = (kCkDw + 3) / 4;         // 673 sixteen-byte pieces leave per chunk
+constexpr int kIlThreads = 384;                    // six waves, two tasks per thread
+constexpr int kIlIts = (kIlTasks + kIlThreads - 1) / kIlThreads;
+constexpr int kPartBytes = kPartGroups * 12;       // 2484 interleaved bytes per part
+constexpr int kIlSegs = kCkBytes / kSegCoded;      // 52 segments of 207 interleaved bytes per chunk (12 to a part)
 
+typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x2a1 __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int V> struct IntC { static constexpr int value = V; };
+#define ATSC_GLOBAL __attribute__((address_space(1)))
+// a wave-uniform address as a scalar register pair: scalar base + 32-bit lane offset is the addressing mode wanted
+__device__ __forceinline__ uint64_t scalar_addr(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 
-__global__ __launch_bounds__(256, 3) void k_interleave(const uint8_t* __restrict__ ts, size_t ts_stride,
-                                                    const uint32_t* __restrict__ parity, const uint8_t* __restrict__ tail,
-                                                    const uint32_t* __restrict__ prbs188, uint8_t* __restrict__ il,
-                                                    size_t il_stride, uint4* __restrict__ par, int channels, int fields,
-                                                    int ch_per_block) {
-    __shared__ uint32_t s_pkt[kIlMaxPk * kIlRowDw];  // 44520 B
-    __shared__ uint32_t s_par[13 * 3][32];           // one XOR accumulator per (part, word, lane mod 32): no same-address traffic
+__global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __restrict__ ts, size_t ts_stride,
+                                                           const uint8_t* __restrict__ parity, const uint8_t* __restrict__ tail,
+                                                           const uint8_t* __restrict__ prbs_rows, uint8_t* __restrict__ il,
+                                                           size_t il_stride, uint32_t* __restrict__ par, int fields,
+                                                           int fields_per_block) {
+    __shared__ uint32_t s_pkt[(kIlRing + kIlMirror) * kIlRowDw];   // 23320 B
+    __shared__ __align__(16) uint32_t s_out[kCkDw + 5];            // the chunk in transmission order
+    __shared__ uint32_t s_par[8 * 3];                              // XOR of the data dwords per (part mod 8, word)
     const int tid = threadIdx.x;
-    const int h = blockIdx.x;                          // half-field index within the batch
-    const int c_lo = blockIdx.y * ch_per_block, c_hi = min(channels, c_lo + ch_per_block);
-    const int total = fields * kPackets;
-    const int o0 = h * kIlBytes - kTail;               // coded offset (batch-relative) of the first byte needed
-    const int q0 = (o0 + 52 * kSegCoded) / kSegCoded - 52;  // floor(o0 / 207), o0 >= -10608 > -52*207
-    const int q1 = (o0 + kIlSrcBytes - 1) / kSegCoded;      // last packet needed (>= 0, < total)
-    const int qa = q0 < 0 ? 0 : q0;                    // first packet that lies in this batch
-    const int ndw = (q1 - qa + 1) * 47;
-    const int npar = (q1 - qa + 1) * 5;
-    const int row0 = qa - q0;
-    constexpr int kLd4 = (kIlMaxPk * 47 + 1023) / 1024;  // 10 x 4 TS dwords per thread
-    constexpr int kLp = (kIlMaxPk * 5 + 255) / 256;    // 5 parity dwords per thread
-    constexpr int kIt = (kIlGroups + 255) / 256;       // 11 groups per thread
+    const int c = blockIdx.y;
+    const int f0 = blockIdx.x * fields_per_block, f1 = min(fields, f0 + fields_per_block);
+    const uint8_t* ts_c = ts + (size_t)c * ts_stride;
+    const uint8_t* rec_c = parity + (size_t)c * fields * (kPackets * 32);
+    uint8_t* il_c = il + (size_t)c * il_stride;
+    if (tid < 8 * 3) s_par[tid] = 0;
 
-    // The PRBS slice of the staged packets does not depend on the channel (it repeats every field = 312*47 dwords):
-    // read once per block, kept in registers.
-    uint32_t prbs[kLd4][4];
+    // This kernel is bound by instruction issue, not by a memory: everything that does not change from chunk to chunk
+    // (task geometry, LDS addresses, offsets from the chunk's base pointers) is computed here, once.
+    // ---- gather tasks: id = 13 hi + lo -> dword column hi (coded bytes 4 hi .. 4 hi + 3 = output rows a0 + 4 j), output
+    // bytes 4 lo .. 4 lo + 3 of those rows
+    bool g_ok[kIlIts], g_all4[kIlIts];
+    const uint32_t* g_src[kIlIts][2];
+    uint32_t* g_dst[kIlIts];
 #pragma unroll
-    for (int k = 0; k < kLd4; ++k)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = 4 * (tid + 256 * k) + j;
-            prbs[k][j] = i < ndw ? prbs188[(qa * 47 + i) % (kPackets * 47)] : 0u;
+    for (int it = 0; it < kIlIts; ++it) {
+        const int id = tid + kIlThreads * it;
+        g_ok[it] = id < kIlTasks;
+        const int hi = id / 13, lo = id - 13 * hi;
+        g_all4[it] = hi < 51;        // column 207 does not exist
+        const int a0 = (16 * hi) % kCkRows;
+        const int first = kCkPk + (52 * a0) / kSegCoded - 4 * lo - 3;   // logical row (0..103: previous chunk, this chunk)
+        // chunk kk lives in half kk & 1: for even kk the previous chunk is rows 52..103 and logical row l is (l + 52) mod 104
+        g_src[it][0] = s_pkt + (first >= kCkPk ? first - kCkPk : first + kCkPk) * kIlRowDw + hi;
+        g_src[it][1] = s_pkt + first * kIlRowDw + hi;
+        g_dst[it] = s_out + a0 * 13 + lo;
+    }
+    // ---- staging tasks: 16 bytes of a packet's LDS row each.  A vector memory instruction costs its pipe the same with 4
+    // lanes active as with 64, so the kinds of task are sorted into whole waves:
+    //   slots 0..571 (first pass: all six waves, second pass: waves 0..2): packet q = slot / 11, piece p = slot % 11: TS bytes
+    //       1 + 16 p .. of the packet, one unaligned load (coded byte t of a packet is TS byte t + 1, randomize.h:48)
+    //   second pass, wave 3: packet q = lane: TS bytes 177..187, the first parity byte and parity bytes 1..4
+    //   second pass, wave 4: packet q = lane: parity bytes 5..19
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int kTsSlots = kCkPk * 11;   // 572
+    // Every lane issues the same loads (no branches between them: a merge of registers after a branch makes the compiler
+    // wait for the data there, which would serialise the prefetch); lanes without a task load offset 0 and drop it.
+    bool st_ok, st_mirror[2];
+    uint32_t a_off[2], pr_off[2], rec_off = 0;
+    uint32_t* st_dst[2][2];
+    {
+        int q[2], p[2];
+        q[0] = tid / 11;
+        p[0] = tid - 11 * q[0];
+        a_off[0] = q[0] * kTsBytes + 1 + 16 * p[0];
+        pr_off[0] = q[0] * 208 + 16 * p[0];
+        if (wave < 3) {
+            const int id = tid + kIlThreads;
+            st_ok = id < kTsSlots;
+            q[1] = st_ok ? id / 11 : 0;
+            p[1] = st_ok ? id - 11 * q[1] : 0;
+            a_off[1] = q[1] * kTsBytes + 1 + 16 * p[1];
+            pr_off[1] = q[1] * 208 + 16 * p[1];
+        } else {
+            st_ok = wave < 5 && lane < kCkPk;
+            q[1] = st_ok ? lane : 0;
+            p[1] = 8 + wave;    // row dwords 44.. / 48..
+            // wave 3: TS bytes 172..187 (aligned; used from byte 177 on) + parity record dwords 0, 1; wave 4: record dwords 2..5
+            a_off[1] = wave == 3 ? q[1] * kTsBytes + 172 : q[1] * 32 + 8;
+            pr_off[1] = q[1] * 208 + (wave == 3 ? 176 : 192);    // row bytes 187..207 of the table are zero
+            rec_off = q[1] * 32;
         }
-    const int g_field0 = (h & 1) * kIlGroups;          // group index of this block's first group within its field
-    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(s_pkt);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            st_mirror[it] = q[it] < kIlMirror;
+            st_dst[it][0] = s_pkt + q[it] * kIlRowDw + 4 * p[it];
+            st_dst[it][1] = st_dst[it][0] + kCkPk * kIlRowDw;
+        }
+    }
+    // ---- leaving: 16-byte piece id of the chunk
+    const uint32_t out_off0 = 16 * tid, out_off1 = 16 * (tid + kIlThreads);
+    const uint4* out_src0 = reinterpret_cast<const uint4*>(s_out) + tid;
+    const uint4* out_src1 = out_src0 + kIlThreads;
+    // ---- trellis parities: thread (segment sg, dword w of a 12-byte group) of the chunk's 52 x 3
+    const int sg = tid / 3, sw = tid - 3 * sg;
+    const int sg_first = (kSegCoded * sg + 11) / 12;
+    const bool sg_18 = (kSegCoded * (sg + 1) + 11) / 12 - sg_first == 18;   // 17 or 18 groups
+    const uint32_t* sg_src = s_out + 3 * sg_first + sw;
 
-    for (int c = c_lo; c < c_hi; ++c) {
-        // index math is redone per channel on purpose (opaque copy of tid): hoisted out of the loop it costs ~100 registers
-        int tid_c = tid;
-        asm volatile("" : "+v"(tid_c));
-        for (int i = tid; i < 13 * 3 * 32; i += 256) (&s_par[0][0])[i] = 0;
-        // packets qa..q1 of this batch: TS dwords ^ PRBS, then parity; every load is issued before the first LDS store
+    u32x4a1 va[2];
+    u32x4 vb[2];
+    u32x2 vr;
+    auto fetch = [&](int kk) {
+        const uint64_t tsk = scalar_addr(reinterpret_cast<uint64_t>(ts_c) + (uint64_t)kk * kCkTs);
+        const uint64_t reck = scalar_addr(reinterpret_cast<uint64_t>(rec_c) + (uint64_t)kk * (kCkPk * 32));
+        const uint64_t prk = scalar_addr(reinterpret_cast<uint64_t>(prbs_rows) + (uint32_t)(kk % kCkPerField) * (kCkPk * 208));
+        const uint64_t base1 = wave == 4 ? reck : tsk;
+        va[0] = *reinterpret_cast<const ATSC_GLOBAL u32x4a1*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(tsk) + a_off[0]);
+        vb[0] = *reinterpret_cast<const ATSC_GLOBAL u32x4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[0]);
+        va[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4a1*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(base1) + a_off[1]);
+        vb[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[1]);
+        vr = *reinterpret_cast<const ATSC_GLOBAL u32x2*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(reck) + rec_off);
+    };
+    auto commit = [&](auto half_c) {
+        constexpr int H = decltype(half_c)::value;
+        uint32_t a1[4] = {va[1].x, va[1].y, va[1].z, va[1].w}, e1 = 0;
+        if (wave == 3) {
+            // loaded TS bytes 172..187; coded bytes 176..186 are TS bytes 177..187; then the first parity byte (already in
+            // the top byte, k_rs_parity) and parity bytes 1..4
+            a1[0] = __builtin_amdgcn_alignbyte(a1[2], a1[1], 1);
+            a1[1] = __builtin_amdgcn_alignbyte(a1[3], a1[2], 1);
+            a1[2] = a1[3] >> 8;
+            a1[3] = vr.y;
+            e1 = vr.x;
+        }
         {
-            const uint32_t* src = reinterpret_cast<const uint32_t*>(ts + (size_t)c * ts_stride) + (size_t)qa * 47;
-            const uint32_t* pp = parity + ((size_t)c * total + qa) * 8;
-            u32x4a4 v[kLd4];
-            uint32_t pv[kLp];
-            const int ndw4 = ndw & ~3;                   // ndw is a multiple of 47; the last 0..3 dwords go one by one
-#pragma unroll
-            for (int k = 0; k < kLd4; ++k) {
-                const int i = 4 * (tid_c + 256 * k);
-                if (i < ndw4) v[k] = *reinterpret_cast<const u32x4a4*>(src + i);
-                else {
-                    v[k].x = i < ndw ? src[i] : 0u;
-                    v[k].y = i + 1 < ndw ? src[i + 1] : 0u;
-                    v[k].z = i + 2 < ndw ? src[i + 2] : 0u;
-                    v[k].w = 0u;
-                }
+            uint32_t* dst = st_dst[0][H];
+            const uint32_t x0 = va[0].x ^ vb[0].x, x1 = va[0].y ^ vb[0].y, x2 = va[0].z ^ vb[0].z, x3 = va[0].w ^ vb[0].w;
+            dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+            if (H == 0 && st_mirror[0]) {
+                dst += kIlRing * kIlRowDw;
+                dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
             }
-#pragma unroll
-            for (int k = 0; k < kLp; ++k) {
-                const int i = tid_c + 256 * k;
-                pv[k] = i < npar ? pp[(i / 5) * 8 + i % 5] : 0u;
+        }
+        if (st_ok) {
+            uint32_t* dst = st_dst[1][H];
+            const uint32_t x0 = a1[0] ^ vb[1].x, x1 = a1[1] ^ vb[1].y, x2 = (a1[2] ^ vb[1].z) | e1, x3 = a1[3] ^ vb[1].w;
+            dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+            if (H == 0 && st_mirror[1]) {
+                dst += kIlRing * kIlRowDw;
+                dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
             }
+        }
+    };
+
+    // ---- the chunk before the block's first one (odd: half 1): from the batch, or from the coded tail of the previous batch
+    const int kk_first = f0 * kCkPerField, kk_end = f1 * kCkPerField;
+    if (kk_first > 0) {
+        fetch(kk_first - 1);
+        commit(IntC<1>());
+    } else {
+        // the last 51 packets before the batch (= the last 10557 bytes of the tail) -> rows 1..51 of half 1
+        uint8_t* rows = reinterpret_cast<uint8_t*>(s_pkt + kCkPk * kIlRowDw);
+        const uint8_t* tl = tail + (size_t)c * kTail + (kTail - 51 * kSegCoded);
+        for (int i = tid; i < 51 * kSegCoded; i += kIlThreads) {
+            const int q = i / kSegCoded, t = i - q * kSegCoded;
+            rows[(1 + q) * (kIlRowDw * 4) + t] = tl[i];
+        }
+    }
+    fetch(kk_first);
+    commit(IntC<0>());
+    __syncthreads();
+
+    // one chunk: kk in the batch, kf in its field (kf & 1 == H)
+    auto chunk = [&](int kk, int kf, int f, auto half_c) {
+        constexpr int H = decltype(half_c)::value;
+        const bool more = kk + 1 < kk_end;
+        if (more) fetch(kk + 1);      // in flight during the gather
+        // ---- gather: seven rows of one dword column -> four output dwords (byte j of rows first + 3 + j - e, e = 0..3)
 #pragma unroll
-            for (int k = 0; k < kLd4; ++k) {
-                const uint32_t vv[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        for (int it = 0; it < kIlIts; ++it) {
+            if (g_ok[it]) {
+                const uint32_t* src = g_src[it][H];
+                uint32_t rw[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) rw[i] = src[i * kIlRowDw];
+                uint32_t* dst = g_dst[it];
+                uint32_t o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int i = 4 * (tid_c + 256 * k) + j;
-                    if (i < ndw) s_pkt[row0 * kIlRowDw + i + 6 * (i / 47)] = vv[j] ^ prbs[k][j];
+                    constexpr uint32_t kPick = 0x0c0c0400u;   // byte 0 <- second operand, byte 1 <- first operand; + j: byte j of each
+                    const uint32_t lo2 = __builtin_amdgcn_perm(rw[2 + j], rw[3 + j], kPick + 0x0101u * j);
+                    const uint32_t hi2 = __builtin_amdgcn_perm(rw[j], rw[1 + j], kPick + 0x0101u * j);
+                    o[j] = lo2 | (hi2 << 16);
                 }
-            }
-#pragma unroll
-            for (int k = 0; k < kLp; ++k) {
-                const int i = tid_c + 256 * k;
-                if (i < npar) s_pkt[(row0 + i / 5) * kIlRowDw + 47 + i % 5] = pv[k];
-            }
-        }
-        // packets before the batch: coded byte o (-10608 <= o < 0) = tail[10608 + o]
-        if (q0 < 0) {
-            const uint8_t* tl = tail + (size_t)c * kTail;
-            uint8_t* s8w = reinterpret_cast<uint8_t*>(s_pkt);
-            for (int i = tid; i < kTail; i += 256) {
-                const int q = (i + (52 * kSegCoded - kTail)) / kSegCoded - 52;  // floor((i - 10608) / 207)
-                const int r = i - kTail - q * kSegCoded;
-                s8w[(q - q0) * (kIlRowDw * 4) + 1 + r] = tl[i];
+                dst[0] = o[0]; dst[52] = o[1]; dst[104] = o[2];
+                if (g_all4[it]) dst[156] = o[3];
             }
         }
         __syncthreads();
-
-        uint8_t* dst = il + (size_t)c * il_stride + (size_t)h * kIlBytes;
+        // ---- the chunk leaves as 16-byte pieces
+        const uint64_t dst = scalar_addr(reinterpret_cast<uint64_t>(il_c) + (uint64_t)kk * kCkBytes);
+        {
+            const uint4 v = *out_src0;
+            u32x4a4 o;
+            o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+            *reinterpret_cast<ATSC_GLOBAL u32x4a4*>(reinterpret_cast<ATSC_GLOBAL uint8_t*>(dst) + out_off0) = o;
+        }
+        if (wave < 5) {
+            const uint4 v = *out_src1;       // pieces 384..672 (s_out is padded)
+            if (out_off1 < 16 * (kIlPieces - 1)) {
+                u32x4a4 o;
+                o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
+                *reinterpret_cast<ATSC_GLOBAL u32x4a4*>(reinterpret_cast<ATSC_GLOBAL uint8_t*>(dst) + out_off1) = o;
+            } else if (out_off1 == 16 * (kIlPieces - 1)) {
+                u32x3a4 o;
+                o.x = v.x; o.y = v.y; o.z = v.z;
+                *reinterpret_cast<ATSC_GLOBAL u32x3a4*>(reinterpret_cast<ATSC_GLOBAL uint8_t*>(dst) + out_off1) = o;
+            }
+        }
+        // ---- precoder / trellis parities of the chunk's 52 segments (reference: trellis.h:240-242).  The parity is linear in
+        // the data bits, so the raw dwords are XORed here, per (part, 4-encoder word), and the parity is taken once per part:
+        // within a segment the encoder assignment does not rotate (trellis_bits.h)
+        if (wave < 3 && tid < kIlSegs * 3) {
+            uint32_t acc = sg_18 ? sg_src[3 * 17] : 0u;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) acc ^= sg_src[3 * i];
+            const int r = 4 * kf + sg;                       // segment of the field = 48 kf + r, r < 72
+            const int S = kf * kIlSegs + sg;
+            atomicXor(&s_par[((4 * kf + r / 12) & 7) * 3 + (sw + S) % 3], acc);
+        }
+        if (more) commit(IntC<H ^ 1>());
+        __syncthreads();
+        // ---- parts that ended inside this chunk are complete
+        const int done_before = (kf * kCkBytes) / kPartBytes, done_after = ((kf + 1) * kCkBytes) / kPartBytes;
+        if (tid < (done_after - done_before) * 3) {
+            const int pi = tid / 3, k = tid - 3 * pi;
+            const int slot = ((done_before + pi) & 7) * 3 + k;
+            uint32_t* o = par + (((size_t)c * fields + f) * kParts + done_before + pi) * 4;
+            uint32_t z2, z0, pr;
+            trellis_local(s_par[slot], z2, z0, pr);
+            o[k] = pr;
+            if (k == 0) o[3] = 0;
+            s_par[slot] = 0;
+        }
+    };
+    int kk = kk_first;
 #pragma unroll 1
-        for (int it = 0; it < kIt; ++it) {
-            const int g = tid_c + 256 * it;
-            if (g < kIlGroups) {
-                uint32_t dw[3];
-#pragma unroll
-                for (int w = 0; w < 3; ++w) {
-                    const int d = 3 * g + w;
-                    const int a = d / 13;
-                    const int r = 4 * (d - 13 * a);
-                    const int abs0 = o0 + (a + 204 - 4 * r) * 52 + r;        // coded offset of byte 0; byte j sits 207*j earlier
-                    const int q = (abs0 + 52 * kSegCoded) / kSegCoded - 52;   // floor
-                    const int addr = (q - q0) * (kIlRowDw * 4) + 1 + (abs0 - q * kSegCoded);
-                    dw[w] = (uint32_t)s8[addr] | ((uint32_t)s8[addr - kIlRowDw * 4] << 8) |
-                            ((uint32_t)s8[addr - 2 * kIlRowDw * 4] << 16) | ((uint32_t)s8[addr - 3 * kIlRowDw * 4] << 24);
-                }
-                u32x3a4 o3;
-                o3.x = dw[0]; o3.y = dw[1]; o3.z = dw[2];
-                // non-temporal: the block's neighbours re-read a third of its TS packets, which the output stream would
-                // otherwise push out of the L2 (0.224 -> 0.210 ms per launch)
-                __builtin_nontemporal_store(o3, reinterpret_cast<u32x3a4*>(dst + 12 * g));
-                // parities of this byte-time for the 12 encoders
-                const Words3 e = canonical_group(dw, g_field0 + g);
-                const int p = g / kPartGroups;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    uint32_t z2, z0, pr;
-                    trellis_local(e.w[k], z2, z0, pr);
-                    atomicXor(&s_par[3 * p + k][tid & 31], pr);
-                }
-            }
+    for (int f = f0; f < f1; ++f) {
+#pragma unroll 1
+        for (int kf = 0; kf < kCkPerField; kf += 2) {
+            chunk(kk, kf, f, IntC<0>());
+            chunk(kk + 1, kf + 1, f, IntC<1>());
+            kk += 2;
         }
-        __syncthreads();
-        if (tid < 13 * 3) {  // fold the 32 slots (rotated start: conflict-free), then one uint4 per part
-            uint32_t v = 0;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) v ^= s_par[tid][(i + tid) & 31];
-            s_par[tid][0] = v;
-        }
-        __syncthreads();
-        if (tid < 13) {
-            const int f = h >> 1;
-            par[((size_t)c * fields + f) * kParts + (h & 1) * 13 + tid] =
-                make_uint4(s_par[3 * tid][0], s_par[3 * tid + 1][0], s_par[3 * tid + 2][0], 0);
-        }
-        __syncthreads();  // s_pkt and s_par are rewritten for the next channel
     }
 }
 
@@ -358,16 +491,19 @@ __global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ t
     const int o = total * kSegCoded - kTail + i;   // >= 0: a batch is at least one field
     const int q = o / kSegCoded, r = o - q * kSegCoded;
     const uint8_t v = r < 187 ? (uint8_t)(ts[(size_t)c * ts_stride + (size_t)q * kTsBytes + 1 + r] ^ prbs[(q % kPackets) * 187 + r])
-                              : parity[((size_t)c * total + q) * 32 + (r - 187)];
+                              : parity[((size_t)c * total + q) * 32 + 3 + (r - 187)];
     tail[(size_t)c * kTail + i] = v;
 }
 
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                        int channels, int fields) {
-    const int cpb = kIlChPerBlock;
-    dim3 grid(2 * fields, (channels + cpb - 1) / cpb);
-    hipLaunchKernelGGL(k_interleave, grid, dim3(256), 0, s, d_ts, ts_stride, reinterpret_cast<const uint32_t*>(b.parity),
-                       b.tail, t.prbs188, b.il, b.il_stride, b.par, channels, fields, cpb);
+    // blocks of whole fields (a part's parity must not be shared between blocks): about four blocks per CU when the batch
+    // is large enough, never more than 16 fields per block (a block re-reads one chunk in front of its fields)
+    int fpb = (int)(((long)channels * fields + 1279) / 1280);
+    fpb = fpb < 1 ? 1 : (fpb > 16 ? 16 : fpb);
+    dim3 grid((fields + fpb - 1) / fpb, channels);
+    hipLaunchKernelGGL(k_interleave, grid, dim3(kIlThreads), 0, s, d_ts, ts_stride, reinterpret_cast<const uint8_t*>(b.parity),
+                       b.tail, t.prbs_rows, b.il, b.il_stride, reinterpret_cast<uint32_t*>(b.par), fields, fpb);
     // the tail is consumed above and replaced by this batch's own (stream order)
     hipLaunchKernelGGL(k_save_tail, dim3((kTail + 255) / 256, channels), dim3(256), 0, s, d_ts, ts_stride,
                        reinterpret_cast<const uint8_t*>(b.parity), t.prbs, b.tail, fields);
