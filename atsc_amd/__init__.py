@@ -47,7 +47,7 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
 
 
 class AtscHipError(RuntimeError):
-    pass
+    code = None   # the C-ABI return code, when the error came from one
 
 
 class Config(C.Structure):
@@ -70,6 +70,7 @@ FIELD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint)
 CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
 FIR_AUTO, FIR_FFT, FIR_MFMA, FIR_FUSED = 0, 1, 2, 3
+ERR_ARG, ERR_NO_DEVICE, ERR_TOO_LARGE, ERR_STATE = -1, -2, -3, -4   # include/atsc_hip.h
 
 _lib = None
 
@@ -146,7 +147,9 @@ def load_library():
 
 def check(rc):
     if rc != 0:
-        raise AtscHipError(f"atsc_hip error {rc}: {load_library().atsc_hip_error_string(rc).decode()}")
+        err = AtscHipError(f"atsc_hip error {rc}: {load_library().atsc_hip_error_string(rc).decode()}")
+        err.code = rc
+        raise err
 
 
 class Encoder:

@@ -275,8 +275,17 @@ int run_back(atsc_hip_encoder* e, const uint4* carry_xor, int fields, uint8_t* d
 
 // which form of the mixer + FIR this batch runs (include/atsc_hip.h, atsc_hip_set_fir_form).  A function of the handle's
 // channel count and its fir_form setting only, so every rank of a time-split picks the same one for equal handles.
+// The matrix-core kernels address a group of 16 channel rows through one buffer descriptor with 32-bit offsets: 16 rows of
+// the largest batch's IQ (max_fields x 260416 samples) must stay below 4 GiB -- 128 fields of complex64, 257 of CS16.  A
+// property of the handle (not of a batch), so that equal handles pick equal forms.
+bool matrix_forms_fit(const atsc_hip_encoder* e, int iq_format) {
+    const uint64_t row_bytes = (uint64_t)e->cfg.max_fields * kFieldSyms * atsc_hip_iq_sample_bytes(iq_format);
+    return 16 * row_bytes <= 0xffffffffull;
+}
+
 int resolve_fir_form(const atsc_hip_encoder* e) {
     if (e->fir_form != ATSC_HIP_FIR_AUTO) return e->fir_form;
+    if (!matrix_forms_fit(e, e->iq_format)) return ATSC_HIP_FIR_FFT;
     // The fused kernel works on groups of kFusedGroup channels and costs the same for a partly filled group, the FFT
     // form costs per channel: fused when at least 80 % of the matrix columns carry a channel.
     const int groups = (e->cfg.channels + kFusedGroup - 1) / kFusedGroup;
@@ -445,6 +454,7 @@ extern "C" size_t atsc_hip_iq_sample_bytes(int format) {
 extern "C" int atsc_hip_set_fir_form(atsc_hip_encoder* e, int form) {
     if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_FUSED) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if ((form == ATSC_HIP_FIR_MFMA || form == ATSC_HIP_FIR_FUSED) && !matrix_forms_fit(e, e->iq_format)) return ATSC_HIP_ERR_TOO_LARGE;
     e->fir_form = form;
     return ATSC_HIP_OK;
 }
@@ -457,6 +467,7 @@ extern "C" int atsc_hip_get_fir_form(atsc_hip_encoder* e) {
 extern "C" int atsc_hip_set_iq_format(atsc_hip_encoder* e, int format) {
     if (!e || !atsc_hip_iq_sample_bytes(format)) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if ((e->fir_form == ATSC_HIP_FIR_MFMA || e->fir_form == ATSC_HIP_FIR_FUSED) && !matrix_forms_fit(e, format)) return ATSC_HIP_ERR_TOO_LARGE;
     e->iq_format = format;
     return ATSC_HIP_OK;
 }

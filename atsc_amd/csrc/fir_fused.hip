@@ -214,9 +214,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         const_cast<float*>(a.planes) + (size_t)f * 2 * kPaddedSyms, 0, 2 * kPaddedSyms * 4, kRsrcFlags);
     const int osc_off = ((lane >> 5) * kPaddedSyms + (lane & 31)) * 4;   // lanes 0..31 the re plane, 32..63 the im plane
     auto osc_fetch = [&](int tile) {   // the 32 newest inputs of `tile`; tiles past the field stay inside the padded table
-#if defined(EXP_NOLOADS) || defined(EXP_NOOSC)
-        return 1.0f + 0.001f * tile;
-#endif
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_osc, osc_off, ((tile < kTiles ? tile : 0) * kTile + 112) * 4, 0));
     };
 
@@ -330,11 +327,7 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         }
     }
     auto il_fetch = [&](int g, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
-#ifdef EXP_ILHOT
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.il) + 3 * (lane + 64 * (g & 7));
-#else
         const uint32_t* src = reinterpret_cast<const uint32_t*>(il_c) + 3 * min(g + pq, kByteTimes - 1);
-#endif
         d0 = src[0]; d1 = src[1]; d2 = src[2];
     };
     // four byte-times: slot pq takes next_g + pq, whose three interleaved dwords are d0..d2
@@ -493,14 +486,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         // load issued at production time would wait, in order, behind every IQ store of the round)
         uint32_t pa0 = 0, pa1 = 0, pa2 = 0, pb0 = 0, pb1 = 0, pb2 = 0;
         const bool pre_ok = fs_j < 0;
-#if !defined(EXP_NOLOADS) && !defined(EXP_NOIL)
         if constexpr (FUSED) {
             il_fetch(next_g, pa0, pa1, pa2);
             il_fetch(next_g + 4, pb0, pb1, pb2);
         }
-#else
-        pa0 = pa1 = pa2 = pb0 = pb1 = pb2 = (uint32_t)(Tg * 0x01030507u);
-#endif
 #pragma unroll
         for (int u = 0; u < kRound; ++u) {
             const int tile = Tg + u;
@@ -551,18 +540,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                     const uint32_t dw = d ? sy[s].y : sy[s].x;
                     const uint4 t = tw[2 * s + d];
                     uint32_t h0, l0, h1, l1;
-#ifdef EXP_NOGEN
-                    h0 = dw ^ t.x; l0 = dw ^ t.w; h1 = dw ^ t.y; l1 = dw ^ t.z;
-#else
                     mix_quad(dw, t, h0, l0, h1, l1);
-#endif
                     if (d == 0) { bhi[slot].x = h0; bhi[slot].y = h1; blo[slot].x = l0; blo[slot].y = l1; }
                     else        { bhi[slot].z = h0; bhi[slot].w = h1; blo[slot].z = l0; blo[slot].w = l1; }
                 }
-#ifdef EXP_NOOUT
-                if (i == 14) asm volatile("" ::"v"(y[0]), "v"(y[5]), "v"(y[10]), "v"(y[15]));
-                if (a.channels < 0)
-#endif
                 if (i >= 14 && i <= 17) {
                     // C -> line image: register e of lane (n, h) is output row (e & 3) + 8 (e >> 2) + 4 h of column n
 #pragma unroll
@@ -583,9 +564,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                 if (i >= 20 && i < 20 + G::kStores) {
                     const int q = i - 20;
                     const uint4 v = piece[q];
-#ifdef EXP_NOSTORE
-                    if (a.channels < 0)
-#endif
                     // non-temporal: the IQ is written once and never read back by the GPU
                     __builtin_amdgcn_raw_buffer_store_b128((v4u){v.x, v.y, v.z, v.w}, rs_iq, (int)(st_off + q * st_step), st_soff, 2);
                 }
@@ -595,10 +573,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
             for (int ks = 0; ks < kKSteps; ++ks) {
                 const int slot = (2 * u + ks) % kKSteps;
                 const h8 bh = __builtin_bit_cast(h8, bhi[slot]), bl = __builtin_bit_cast(h8, blo[slot]);
-#ifdef EXP_NOMFMA
-                acc[ks] += (float)bh[0] + (float)bl[1] + (float)ahi[ks][2];
-                side(3 * ks); side(3 * ks + 1); side(3 * ks + 2);
-#else
                 const h8 ah = ahi[ks], al = alo[ks];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
                 side(3 * ks);
@@ -606,15 +580,11 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                 side(3 * ks + 1);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
                 side(3 * ks + 2);
-#endif
             }
             acc_prev = acc;
         }
         if constexpr (FUSED) {
             // the ring moves on to what the next round reads (nothing is needed behind the run's last tile unless the tap wants it)
-#ifdef EXP_NOPROD
-            if (a.channels < 0)
-#endif
             if (r + 1 < a.rounds || a.sym) {
                 lds_order();
                 const int limit = (Tg + 2 * kRound + 4) * kTile + 16;
@@ -639,9 +609,6 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
 #pragma unroll
         for (int q = 0; q < G::kStores; ++q) {
             const uint4 v = *reinterpret_cast<const uint4*>(img_rd + q * G::kRowsPerStore * G::kImgRow);
-#ifdef EXP_NOSTORE
-            if (a.channels < 0)
-#endif
             __builtin_amdgcn_raw_buffer_store_b128((v4u){v.x, v.y, v.z, v.w}, rs_iq, (int)(st_off + q * st_step), tile * G::kRowBytes, 2);
         }
     }
@@ -687,11 +654,7 @@ void launch_mm(hipStream_t s, FirArgs a) {
     a.runs_per_field = (kTiles + kRound * a.rounds - 1) / (kRound * a.rounds);
     const long tasks = (long)a.runs_per_field * a.ch_groups * a.fields;
     const unsigned grid = (unsigned)((tasks + kWaves - 1) / kWaves);
-#ifdef EXP_ONEBLOCK
-    hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED>), dim3(grid), dim3(64 * kWaves), 24000, s, a);
-#else
     hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED>), dim3(grid), dim3(64 * kWaves), 0, s, a);
-#endif
 }
 
 template <bool FUSED>

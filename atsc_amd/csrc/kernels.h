@@ -75,7 +75,7 @@ void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, floa
 void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
                         float2* osc_tab, int channels, int fields, int iq_format);
 hipError_t upload_fft_tables(const float* taps112);
-// Mixer + FIR on the matrix cores for handles with many channels (fir_mfma.hip): osc_planes is the osc_tab memory
+// Mixer + FIR on the matrix cores for handles with many channels (fir_fused.hip, the form without the symbol producer): osc_planes is the osc_tab memory
 // filled by launch_osc_table(..., planes = true).
 void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
                          const float* osc_planes, int channels, int fields, int iq_format);

@@ -338,8 +338,9 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world)
         traffic_src = {"file": "profiles/r02/traffic.json", "commit": tj.get("commit"),
                        "note": "PMC passes of scripts/pmc_traffic.sh on the named commit; not re-measured in this run"}
     roofline = {
-        "kernel": ("k_mix_fir_fused (precoder/trellis/mapper/sync + pilot/offset mixer + 112-tap RRC FIR as a banded "
-                   "fp16 hi/lo GEMM on the matrix cores, symbols regenerated in LDS)" if fused else
+        "kernel": ("k_mix_fir_mm<cf32, fused> (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes, "
+                   "pilot + offset mixer first, then the 112-tap RRC FIR as Y = A.Z with a constant Toeplitz tap operand on the "
+                   "matrix cores, fp16 hi/lo split of both operands)" if fused else
                    "k_mix_fir_fft (pilot/offset mixer + 112-tap RRC FIR, overlap-save 1024-point FFT form)"),
         "bound": "hbm",
         "achieved": round(fir_gbs, 1),

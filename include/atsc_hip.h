@@ -139,8 +139,12 @@ size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown form
  *         regenerated from the interleaved bytes inside the kernel and never pass through HBM.  Only in
  *         atsc_hip_encode_batch / _finish with d_iq != NULL; d_sym is then an optional tap (NULL: no symbols are
  *         written anywhere and atsc_hip_stage_buffer(TRELLIS_MAP) returns ATSC_HIP_ERR_STATE)
- *   AUTO: FUSED when the handle's channels fill at least 80 % of whole groups of 32 (26..32, 52..64, 77..96, ...),
+ *   AUTO: FUSED when the handle's channels fill at least 80 % of whole groups of 16 (13..16, 26..32, 39..48, 52..),
  *         FFT otherwise (default)
+ * MFMA and FUSED address 16 channel rows of a batch's IQ through one 32-bit-offset buffer descriptor: they need
+ * 16 * max_fields * 260416 * atsc_hip_iq_sample_bytes(format) < 4 GiB (max_fields <= 128 for CF32, 257 for CS16, 515
+ * for CS8).  On a larger handle AUTO resolves to FFT, and asking for MFMA / FUSED (or switching such a handle to a wider
+ * sample format) returns ATSC_HIP_ERR_TOO_LARGE.
  * No reference counterpart (the reference has one scalar/AVX form, filter.h:16-69). */
 enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2, ATSC_HIP_FIR_FUSED = 3 };
 int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);

@@ -482,7 +482,7 @@ def test_edge_sizes(torch_cuda):
     assert np.array_equal(sym, Oracle().symbols(ts, nf))
 
 
-# ---- matrix-core form of the mixer + FIR (fir_mfma.hip): handles with >= 16 channels
+# ---- matrix-core form of the mixer + FIR (fir_fused.hip, unfused instance): handles with >= 16 channels
 
 @pytest.mark.parametrize("C_", [16, 33, 40, 64, 70])
 def test_mfma_form_every_channel_against_oracle(torch_cuda, C_):
@@ -620,13 +620,24 @@ def test_fused_bench_path_full_size(torch_cuda, C_, nf):
     assert bool((sym_f == sym_u).all()), "fused symbol tap differs from k_trellis_map"
     assert float((iq_bench - iq_u).abs().max()) <= IQ_TOL, "fused and FFT forms disagree"
     del iq_u, sym_f
+    worst = 0.0
     for c in (0, C_ // 2 + 1, C_ - 1):
         want = Oracle().process_fields(ts[c].cpu().numpy().reshape(-1), nf, want=("sym", "iq"))
         assert np.array_equal(sym_u.view(C_, n)[c].cpu().numpy(), want["sym"]), f"channel {c}"
-        got = iq_bench[c].cpu().numpy()
-        for f in (0, nf - 1):
-            sl = slice(2 * f * FIELD_SYMBOLS, 2 * (f + 1) * FIELD_SYMBOLS)
-            assert np.abs(got[sl] - want["iq"][sl]).max() <= IQ_TOL, f"channel {c} field {f}"
+        err = float(np.abs(iq_bench[c].cpu().numpy() - want["iq"]).max())      # every field of the channel
+        assert err <= IQ_TOL, f"channel {c}: {err}"
+        worst = max(worst, err)
+    if (C_, nf) == (64, 64):
+        # the figure bench.py quotes beside its roofline (copied to profiles/ from gpurun_out/ by hand, with the commit)
+        import json
+        import os
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out) and os.access(out, os.W_OK):
+            json.dump({"max_abs_error": worst, "tolerance": IQ_TOL, "full_scale": 1.0,
+                       "checked": "channels 0, 33 and 63 of 64, all 64 fields each, fused form against the oracle; every channel "
+                                  "against the FFT form within the same tolerance (tests/test_gpu_parity.py::"
+                                  "test_fused_bench_path_full_size)"},
+                      open(os.path.join(out, "fused_iq_error.json"), "w"), indent=1)
 
 
 def test_fused_randomised_cross_check(torch_cuda):

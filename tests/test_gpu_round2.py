@@ -239,3 +239,25 @@ def test_reference_null_driver_runs_on_the_drop_in(torch_cuda, tmp_path):
     out = subprocess.run([exe, str(path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-1000:]
     assert "Failed" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_matrix_core_forms_respect_the_descriptor_limit():
+    """16 channel rows of the largest batch's IQ must fit one 32-bit-offset buffer descriptor (include/atsc_hip.h): a
+    handle of 129 complex64 fields resolves AUTO to FFT and refuses MFMA / FUSED; with CS16 samples the same handle fits."""
+    e = atsc_amd.Encoder(channels=16, max_fields=129)
+    assert e.fir_form() == atsc_amd.FIR_FFT
+    for form in (atsc_amd.FIR_MFMA, atsc_amd.FIR_FUSED):
+        with pytest.raises(atsc_amd.AtscHipError) as err:
+            e.set_fir_form(form)
+        assert err.value.code == atsc_amd.ERR_TOO_LARGE
+    e.set_iq_format(atsc_amd.IQ_CS16)
+    assert e.fir_form() == atsc_amd.FIR_FUSED
+    e.set_fir_form(atsc_amd.FIR_FUSED)
+    with pytest.raises(atsc_amd.AtscHipError) as err:
+        e.set_iq_format(atsc_amd.IQ_CF32)
+    assert err.value.code == atsc_amd.ERR_TOO_LARGE
+    e.close()
+    e = atsc_amd.Encoder(channels=16, max_fields=128)
+    assert e.fir_form() == atsc_amd.FIR_FUSED
+    e.close()
