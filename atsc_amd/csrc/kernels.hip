@@ -224,13 +224,26 @@ constexpr int kIlRing = 2 * kCkPk;                 // 104 packet rows: two chunk
 constexpr int kIlMirror = 6;                       // rows 104..109 repeat rows 0..5: a window of 7 rows never wraps
 constexpr int kIlTasks = kCkPk * 13;               // 676 = (packet, 16-byte piece) when staging = (dword column, 4 rows) when gathering
 constexpr int kIlPieces = (kCkDw + 3) / 4;         // 673 sixteen-byte pieces leave per chunk
-constexpr int kIlThreads = 384;                    // six waves, two tasks per thread
-constexpr int kIlIts = (kIlTasks + kIlThreads - 1) / kIlThreads;
-constexpr int kPartBytes = kPartGroups * 12;       // 2484 interleaved bytes per part
 constexpr int kIlSegs = kCkBytes / kSegCoded;      // 52 segments of 207 interleaved bytes per chunk (12 to a part)
+// Eight waves: a workgroup then puts two waves on every SIMD whatever SIMD its first wave lands on, so up to three workgroups
+// (the register budget: 80 VGPRs = 6 waves per SIMD) always fit a CU.  With six waves the fourth workgroup often did not fit
+// (one SIMD already held six waves) and the grid ran in two rounds.
+constexpr int kIlThreads = 512;
+constexpr int kIlIts = (kIlTasks + kIlThreads - 1) / kIlThreads;
+static_assert(kIlIts == 2, "two tasks per thread");
+constexpr int kTsSlots = kCkPk * 11;                                         // 572 sixteen-byte pieces of TS data per chunk
+constexpr int kIlTsWaves1 = (kTsSlots - kIlThreads + 63) / 64;              // waves whose second staging task is a TS piece
+constexpr int kIlBWave = kIlTsWaves1, kIlCWave = kIlTsWaves1 + 1;           // waves whose second task is a packet's tail / parity
+constexpr int kIlGatherWaves1 = (kIlTasks - kIlThreads + 63) / 64;          // waves with a second gather task
+constexpr int kIlStoreWaves1 = (kIlPieces - kIlThreads + 63) / 64;          // waves with a second piece to store
+constexpr int kIlParTid0 = 64 * (kIlCWave + 1);                              // the parity threads start behind those waves
+constexpr int kIlFoldTid0 = kIlThreads - 64;                                 // the last wave folds
+static_assert(kIlParTid0 + kIlSegs * 3 <= kIlFoldTid0 + 64, "parity threads");
+constexpr int kPartBytes = kPartGroups * 12;       // 2484 interleaved bytes per part
 
 typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint32_t u32x2a1 __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x1a1 __attribute__((aligned(1)));
 typedef uint32_t u32x4a8 __attribute__((ext_vector_type(4), aligned(8)));
 typedef uint32_t u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -281,14 +294,14 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
     }
     // ---- staging tasks: 16 bytes of a packet's LDS row each.  A vector memory instruction costs its pipe the same with 4
     // lanes active as with 64, so the kinds of task are sorted into whole waves:
-    //   slots 0..571 (first pass: all six waves, second pass: waves 0..2): packet q = slot / 11, piece p = slot % 11: TS bytes
-    //       1 + 16 p .. of the packet, one unaligned load (coded byte t of a packet is TS byte t + 1, randomize.h:48)
-    //   second pass, wave 3: packet q = lane: TS bytes 177..187, the first parity byte and parity bytes 1..4
-    //   second pass, wave 4: packet q = lane: parity bytes 5..19
+    //   slots 0..571 (first task of every thread, second task of the first wave(s)): packet q = slot / 11, piece p = slot % 11:
+    //       TS bytes 1 + 16 p .. of the packet, one unaligned load (coded byte t of a packet is TS byte t + 1, randomize.h:48)
+    //   second task of wave kIlBWave: packet q = lane: TS bytes 177..187, the first parity byte and parity bytes 1..4
+    //   second task of wave kIlCWave: packet q = lane: parity bytes 5..19
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    constexpr int kTsSlots = kCkPk * 11;   // 572
-    // Every lane issues the same loads (no branches between them: a merge of registers after a branch makes the compiler
-    // wait for the data there, which would serialise the prefetch); lanes without a task load offset 0 and drop it.
+    // The lanes of a wave issue the same loads (no lane-dependent branches between them: a merge of registers after such a
+    // branch makes the compiler wait for the data there, which would serialise the prefetch); lanes without a task load
+    // offset 0 and drop it.
     bool st_ok, st_mirror[2];
     uint32_t a_off[2], pr_off[2], rec_off = 0;
     uint32_t* st_dst[2][2];
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         p[0] = tid - 11 * q[0];
         a_off[0] = q[0] * kTsBytes + 1 + 16 * p[0];
         pr_off[0] = q[0] * 208 + 16 * p[0];
-        if (wave < 3) {
+        if (wave < kIlTsWaves1) {
             const int id = tid + kIlThreads;
             st_ok = id < kTsSlots;
             q[1] = st_ok ? id / 11 : 0;
@@ -306,12 +319,12 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
             a_off[1] = q[1] * kTsBytes + 1 + 16 * p[1];
             pr_off[1] = q[1] * 208 + 16 * p[1];
         } else {
-            st_ok = wave < 5 && lane < kCkPk;
+            st_ok = wave <= kIlCWave && lane < kCkPk;
             q[1] = st_ok ? lane : 0;
-            p[1] = 8 + wave;    // row dwords 44.. / 48..
-            // wave 3: TS bytes 172..187 (aligned; used from byte 177 on) + parity record dwords 0, 1; wave 4: record dwords 2..5
-            a_off[1] = wave == 3 ? q[1] * kTsBytes + 172 : q[1] * 32 + 8;
-            pr_off[1] = q[1] * 208 + (wave == 3 ? 176 : 192);    // row bytes 187..207 of the table are zero
+            p[1] = wave == kIlBWave ? 11 : 12;    // row dwords 44.. / 48..
+            // B: TS bytes 172..187 (aligned; used from byte 177 on) + parity record dwords 0, 1; C: record dwords 2..5
+            a_off[1] = wave == kIlBWave ? q[1] * kTsBytes + 172 : q[1] * 32 + 8;
+            pr_off[1] = q[1] * 208 + (wave == kIlBWave ? 176 : 192);    // row bytes 187..207 of the table are zero
             rec_off = q[1] * 32;
         }
 #pragma unroll
@@ -324,9 +337,11 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
     // ---- leaving: 16-byte piece id of the chunk
     const uint32_t out_off0 = 16 * tid, out_off1 = 16 * (tid + kIlThreads);
     const uint4* out_src0 = reinterpret_cast<const uint4*>(s_out) + tid;
-    const uint4* out_src1 = out_src0 + kIlThreads;
+    const uint4* out_src1 = tid + kIlThreads < kIlPieces ? out_src0 + kIlThreads : out_src0;
     // ---- trellis parities: thread (segment sg, dword w of a 12-byte group) of the chunk's 52 x 3
-    const int sg = tid / 3, sw = tid - 3 * sg;
+    const int pt = tid - kIlParTid0;
+    const bool pt_ok = pt >= 0 && pt < kIlSegs * 3;
+    const int sg = pt_ok ? pt / 3 : 0, sw = pt_ok ? pt - 3 * sg : 0;
     const int sg_first = (kSegCoded * sg + 11) / 12;
     const bool sg_18 = (kSegCoded * (sg + 1) + 11) / 12 - sg_first == 18;   // 17 or 18 groups
     const uint32_t* sg_src = s_out + 3 * sg_first + sw;
@@ -338,17 +353,19 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         const uint64_t tsk = scalar_addr(reinterpret_cast<uint64_t>(ts_c) + (uint64_t)kk * kCkTs);
         const uint64_t reck = scalar_addr(reinterpret_cast<uint64_t>(rec_c) + (uint64_t)kk * (kCkPk * 32));
         const uint64_t prk = scalar_addr(reinterpret_cast<uint64_t>(prbs_rows) + (uint32_t)(kk % kCkPerField) * (kCkPk * 208));
-        const uint64_t base1 = wave == 4 ? reck : tsk;
+        const uint64_t base1 = wave == kIlCWave ? reck : tsk;
         va[0] = *reinterpret_cast<const ATSC_GLOBAL u32x4a1*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(tsk) + a_off[0]);
         vb[0] = *reinterpret_cast<const ATSC_GLOBAL u32x4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[0]);
-        va[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4a1*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(base1) + a_off[1]);
-        vb[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[1]);
-        vr = *reinterpret_cast<const ATSC_GLOBAL u32x2*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(reck) + rec_off);
+        if (wave <= kIlCWave) {      // (wave-uniform)
+            va[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4a1*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(base1) + a_off[1]);
+            vb[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[1]);
+            vr = *reinterpret_cast<const ATSC_GLOBAL u32x2*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(reck) + rec_off);
+        }
     };
     auto commit = [&](auto half_c) {
         constexpr int H = decltype(half_c)::value;
         uint32_t a1[4] = {va[1].x, va[1].y, va[1].z, va[1].w}, e1 = 0;
-        if (wave == 3) {
+        if (wave == kIlBWave) {
             // loaded TS bytes 172..187; coded bytes 176..186 are TS bytes 177..187; then the first parity byte (already in
             // the top byte, k_rs_parity) and parity bytes 1..4
             a1[0] = __builtin_amdgcn_alignbyte(a1[2], a1[1], 1);
@@ -383,12 +400,28 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         fetch(kk_first - 1);
         commit(IntC<1>());
     } else {
-        // the last 51 packets before the batch (= the last 10557 bytes of the tail) -> rows 1..51 of half 1
-        uint8_t* rows = reinterpret_cast<uint8_t*>(s_pkt + kCkPk * kIlRowDw);
+        // the last 51 packets before the batch (= the last 10557 bytes of the tail) -> rows 1..51 of half 1, as unaligned
+        // dwords with every load in flight at once: 64 of the grid's blocks come through here, and a slow copy here is the
+        // kernel's tail (the last dword of a row reads three bytes of the next packet into the row's padding; the very
+        // last one would read past the tail and is assembled from bytes)
+        uint32_t* rows = s_pkt + (kCkPk + 1) * kIlRowDw;
         const uint8_t* tl = tail + (size_t)c * kTail + (kTail - 51 * kSegCoded);
-        for (int i = tid; i < 51 * kSegCoded; i += kIlThreads) {
-            const int q = i / kSegCoded, t = i - q * kSegCoded;
-            rows[(1 + q) * (kIlRowDw * 4) + t] = tl[i];
+        constexpr int kTailDw = 51 * 52;
+        constexpr int kTailIts = (kTailDw + kIlThreads - 1) / kIlThreads;
+        uint32_t tv[kTailIts];
+#pragma unroll
+        for (int it = 0; it < kTailIts; ++it) {
+            const int i = tid + kIlThreads * it;
+            const int q = i / 52, w = i - 52 * q;
+            tv[it] = 0;
+            if (i < kTailDw - 1) tv[it] = *reinterpret_cast<const u32x1a1*>(tl + q * kSegCoded + 4 * w);
+            else if (i == kTailDw - 1) tv[it] = tl[50 * kSegCoded + 204] | (tl[50 * kSegCoded + 205] << 8) | (tl[50 * kSegCoded + 206] << 16);
+        }
+#pragma unroll
+        for (int it = 0; it < kTailIts; ++it) {
+            const int i = tid + kIlThreads * it;
+            const int q = i / 52, w = i - 52 * q;
+            if (i < kTailDw) rows[q * kIlRowDw + w] = tv[it];
         }
     }
     fetch(kk_first);
@@ -403,6 +436,7 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         // ---- gather: seven rows of one dword column -> four output dwords (byte j of rows first + 3 + j - e, e = 0..3)
 #pragma unroll
         for (int it = 0; it < kIlIts; ++it) {
+            if (it == 1 && wave >= kIlGatherWaves1) break;      // (wave-uniform)
             if (g_ok[it]) {
                 const uint32_t* src = g_src[it][H];
                 uint32_t rw[7];
@@ -430,8 +464,8 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
             o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
             *reinterpret_cast<ATSC_GLOBAL u32x4a4*>(reinterpret_cast<ATSC_GLOBAL uint8_t*>(dst) + out_off0) = o;
         }
-        if (wave < 5) {
-            const uint4 v = *out_src1;       // pieces 384..672 (s_out is padded)
+        if (wave < kIlStoreWaves1) {
+            const uint4 v = *out_src1;       // the pieces behind the first kIlThreads (s_out is padded)
             if (out_off1 < 16 * (kIlPieces - 1)) {
                 u32x4a4 o;
                 o.x = v.x; o.y = v.y; o.z = v.z; o.w = v.w;
@@ -445,7 +479,7 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         // ---- precoder / trellis parities of the chunk's 52 segments (reference: trellis.h:240-242).  The parity is linear in
         // the data bits, so the raw dwords are XORed here, per (part, 4-encoder word), and the parity is taken once per part:
         // within a segment the encoder assignment does not rotate (trellis_bits.h)
-        if (wave < 3 && tid < kIlSegs * 3) {
+        if (pt_ok) {
             uint32_t acc = sg_18 ? sg_src[3 * 17] : 0u;
 #pragma unroll
             for (int i = 0; i < 17; ++i) acc ^= sg_src[3 * i];
@@ -457,8 +491,9 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         __syncthreads();
         // ---- parts that ended inside this chunk are complete
         const int done_before = (kf * kCkBytes) / kPartBytes, done_after = ((kf + 1) * kCkBytes) / kPartBytes;
-        if (tid < (done_after - done_before) * 3) {
-            const int pi = tid / 3, k = tid - 3 * pi;
+        const int ft = tid - kIlFoldTid0;
+        if (ft >= 0 && ft < (done_after - done_before) * 3) {
+            const int pi = ft / 3, k = ft - 3 * pi;
             const int slot = ((done_before + pi) & 7) * 3 + k;
             uint32_t* o = par + (((size_t)c * fields + f) * kParts + done_before + pi) * 4;
             uint32_t z2, z0, pr;
@@ -497,9 +532,12 @@ __global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ t
 
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                        int channels, int fields) {
-    // blocks of whole fields (a part's parity must not be shared between blocks): about four blocks per CU when the batch
-    // is large enough, never more than 16 fields per block (a block re-reads one chunk in front of its fields)
-    int fpb = (int)(((long)channels * fields + 1279) / 1280);
+    // Workgroups of whole fields (a part's parity must not be shared between workgroups).  Measured at 64 x 64 fields: two
+    // workgroups per CU (512 in all, 8 fields each) 0.153 ms, three 0.164, one 0.22 -- a CU gets through a chunk in about
+    // 1.5 us however many workgroups share it, and one workgroup alone needs 2.3 us per chunk.  Never more than
+    // 16 fields per workgroup (it re-reads one chunk in front of its fields).
+    constexpr int kIlGridTarget = 512;
+    int fpb = (int)(((long)channels * fields + kIlGridTarget - 1) / kIlGridTarget);
     fpb = fpb < 1 ? 1 : (fpb > 16 ? 16 : fpb);
     dim3 grid((fields + fpb - 1) / fpb, channels);
     hipLaunchKernelGGL(k_interleave, grid, dim3(kIlThreads), 0, s, d_ts, ts_stride, reinterpret_cast<const uint8_t*>(b.parity),
