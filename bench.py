@@ -123,6 +123,10 @@ def parse_args(argv=None):
                          "configuration, cs16/cs8 are the SDR sink formats (SURVEY 8f-3)")
     ap.add_argument("--fir-form", choices=("auto", "fft", "mfma", "fused"), default="auto",
                     help="A/B runs: which kernel computes the mixer + FIR (atsc_hip_set_fir_form)")
+    ap.add_argument("--resample", default=None, metavar="L/M",
+                    help="SURVEY 8f-1: follow the encoder with the SDR-rate polyphase resampler (include/atsc_hip_resample.h) "
+                         "inside the timed step; the line gains a `resampler` object with that kernel's own roofline.  Not "
+                         "the headline configuration (the reference runs the radio at the symbol rate)")
     ap.add_argument("--cpu-stub", action="store_true",
                     help="CPU tests: launcher + gloo rendezvous + barrier/max-over-ranks plumbing with the GPU step stubbed")
     args = ap.parse_args(argv)
@@ -371,11 +375,35 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     fused = enc.fir_form() == atsc_amd.FIR_FUSED
     ts = make_ts(torch, C_, F, 1234 + rk.rank)     # seeded per rank: every global channel its own stream
     sym = torch.empty(C_ * F * FIELD_SYMBOLS, dtype=torch.uint8, device="cuda") if args.symbol_tap else None
-    iq = torch.empty(C_ * F * FIELD_SYMBOLS * sample_bytes, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
+    rs = None
+    if args.resample:
+        # the resampler reads complex64: the encoder hands it CF32 and the chosen sample format applies to ITS output
+        L, M = (int(v) for v in args.resample.split("/"))
+        enc.set_iq_format(atsc_amd.IQ_CF32)
+        rs = atsc_amd.Resampler(C_, L, M, 16, out_format=fmt, device=rk.local_rank)
+        n_in = F * FIELD_SYMBOLS
+        n_out = max(rs.out_count(n_in), (n_in * L + M - 1) // M) + 8      # the count moves by one with the carried phase
+        rs_out = torch.empty(C_ * n_out * sample_bytes, dtype=torch.uint8, device="cuda")
+        rs_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        rs_samples = []
+        iq_bytes = 8
+    else:
+        iq_bytes = sample_bytes
+    iq = torch.empty(C_ * F * FIELD_SYMBOLS * iq_bytes, dtype=torch.uint8, device="cuda")
+    step_no = [-args.warmup]
 
     def step():
         enc.encode_batch(ts.data_ptr(), F, sym.data_ptr() if args.symbol_tap else None, iq.data_ptr(), stream)
+        if rs is not None:
+            k = step_no[0]
+            step_no[0] += 1
+            if k >= 0:
+                rs_ev[k][0].record()
+                rs_samples.append(rs.out_count(n_in))
+            rs.resample(iq.data_ptr(), n_in, n_in, rs_out.data_ptr(), n_out, stream)
+            if k >= 0:
+                rs_ev[k][1].record()
 
     for _ in range(args.warmup):
         step()
@@ -392,8 +420,21 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
 
     sym_per_step_gpu = C_ * F * FIELD_SYMBOLS
     msym_s = sym_per_step_gpu * args.steps * rk.world / elapsed / 1e6
-    stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, rk.world)
-    return {
+    stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, iq_bytes, msym_s, rk.world)
+    resampler = None
+    if rs is not None:
+        ms = sum(a.elapsed_time(b) for a, b in rs_ev) / args.steps
+        out_per_ch = sum(rs_samples) / args.steps
+        byts = C_ * (n_in * 8 + out_per_ch * sample_bytes)
+        resampler = {"ratio": args.resample, "taps_per_phase": 16, "out_format": args.iq_format, "avg_launch_ms": round(ms, 4),
+                     "out_msamples_s": round(C_ * out_per_ch / ms / 1e3, 1),
+                     "roofline": {"bound": "hbm", "achieved": round(byts / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": round(byts),
+                                  "note": "8 B complex64 in per symbol + out_format bytes per output sample; kernel time from "
+                                          "events on the launch stream around each call"},
+                     "parity": "unpinned (no reference counterpart); every L-th sample of an integer-L output is the encoder's "
+                               "own IQ bit for bit (tests/test_resample.py)"}
+    res = {
         "metric": METRIC, "value": round(msym_s, 2), "unit": "Msym/s", "n_gpus": rk.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
@@ -411,6 +452,10 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         "roofline": roofline,
         "roofline_other_stages": stages,
     }
+    if resampler:
+        res["resampler"] = resampler
+        res["config"]["workload"] += f" + {args.resample} SDR-rate resampler ({args.iq_format} out) inside the step"
+    return res
 
 
 def bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes):

@@ -7,6 +7,12 @@ size-independent property for full-size batches: decode(enc
 codeword has zero syndromes.  All steps are torch gathers / XORs, so the check runs on the GPU next to the encoder
 (or on the CPU for small cases).
 
+For a signal that is NOT clean there is a maximum-likelihood decoder of the 4-state trellis code in front of that chain
+(`viterbi_symbols`): the convolutional half of the code is Z0[u] = Z1[u-1] ^ Z0[u-2] with Z2 uncoded (parallel
+transitions), so the decoder works on (Z1, Z0) with the nearer of the two Z2 levels as the branch metric.  It is written
+as a parallel scan in the (min, +) semiring instead of a time loop, so a whole stream decodes in a few tensor operations.
+`trellis_violations` is the cheap form: the number of symbols that break the code's parity check (0 for encoder output).
+
 Conventions: data symbol j of data segment s comes from encoder (4s+j) mod 12, symbol number
 t = 69s + j//12 of that encoder in the field; a byte is four (x2,x1) pairs MSB first; Z2[t] = x2[t] ^ Z2[t-1], Z1 = x1;
 encoder e takes, as its g-th byte of the field, IL[12g + ((e - 4*((12g//207) % 3)) mod 12)]; IL[M] = E[M - 208*(M mod 52)].
@@ -107,3 +113,87 @@ def decode_symbols(sym, fields):
     rows = torch.arange((F - 1) * 312, device=sym.device) % 312
     payload = (coded[:, :187] ^ k["prbs"][rows].long()).to(torch.uint8)
     return payload, worst
+
+
+def _per_encoder(x, fields):
+    """[fields*260416] per-symbol values of one stream -> [12, fields*21528]: the data symbols of each encoder in time order."""
+    k = _consts(x.device)
+    F = fields
+    v = x.view(F, SEGS, SEG_SYMS)[:, 1:, 4:].reshape(F, 312 * 828)
+    return v[:, k["sym_of"]].view(F, 12, ENC_SYMS).permute(1, 0, 2).reshape(12, F * ENC_SYMS)
+
+
+def _from_per_encoder(v, like, fields):
+    """inverse of _per_encoder: writes the data symbols back into a copy of `like` ([fields*260416])."""
+    k = _consts(like.device)
+    F = fields
+    out = like.clone().view(F, SEGS, SEG_SYMS)
+    data = torch.empty(F, 312 * 828, dtype=like.dtype, device=like.device)
+    data[:, k["sym_of"]] = v.view(12, F, ENC_SYMS).permute(1, 0, 2).reshape(F, 12 * ENC_SYMS).to(like.dtype)
+    out[:, 1:, 4:] = data.view(F, 312, 828)
+    return out.view(-1)
+
+
+def trellis_violations(sym, fields):
+    """Number of data symbols of a stream (from its first field on) that break Z0[u] = Z1[u-1] ^ Z0[u-2] (zero start state)."""
+    v = _per_encoder(sym.long(), fields)
+    z0, z1 = v & 1, (v >> 1) & 1
+    want = torch.zeros_like(z0)
+    want[:, 1:] = z1[:, :-1]
+    want[:, 2:] ^= z0[:, :-2]
+    return int((want != z0).sum().item())
+
+
+def _minplus(a, b):
+    return (a.unsqueeze(-1) + b.unsqueeze(-3)).amin(dim=-2)
+
+
+def _scan(m):
+    """inclusive prefix products of m[..., t, 4, 4] along t in the (min, +) semiring (Hillis-Steele doubling)."""
+    p = m.clone()
+    T = p.shape[-3]
+    d = 1
+    while d < T:
+        p[..., d:, :, :] = _minplus(p[..., :-d, :, :], p[..., d:, :, :])
+        d *= 2
+    return p
+
+
+def viterbi_symbols(levels, fields):
+    """Maximum-likelihood sequence decision for the data symbols of one stream received from its first field on.
+    levels: float tensor [fields*260416] in level-index units (a clean symbol v arrives as float(v), v = 0..7 <-> the
+    8VSB levels -7..+7).  Returns uint8 [fields*260416]: sync symbols sliced to the nearest level, data
+    symbols decided by the trellis decoder (encoder state zero at the start, free at the end)."""
+    dev = levels.device
+    r = _per_encoder(levels.double(), fields)                   # [12, T]
+    T = r.shape[1]
+    # branch metric for (z1, z0): squared distance to the nearer of the two z2 levels v = 4 z2 + 2 z1 + z0
+    bm = torch.empty(12, T, 2, 2, dtype=torch.float64, device=dev)
+    for z1 in (0, 1):
+        for z0 in (0, 1):
+            lo = 2 * z1 + z0
+            bm[:, :, z1, z0] = torch.minimum((r - lo) ** 2, (r - lo - 4) ** 2)
+    # state s = 2 A + B, A = Z0[u], B = Z0[u-1]; input x1 (= Z1[u]): next state (x1 ^ B, A), emits (Z1, Z0) = (x1, A)
+    inf = float("inf")
+    M = torch.full((12, T, 4, 4), inf, dtype=torch.float64, device=dev)
+    for A in (0, 1):
+        for B in (0, 1):
+            for x1 in (0, 1):
+                M[:, :, 2 * A + B, 2 * (x1 ^ B) + A] = bm[:, :, x1, A]
+    P = _scan(M)                                                # P[t] = M[0] x ... x M[t]
+    alpha = torch.full((12, T + 1, 4), inf, dtype=torch.float64, device=dev)
+    alpha[:, 0, 0] = 0.0                                        # both delays zero at the start of a stream
+    alpha[:, 1:, :] = P[:, :, 0, :]                             # best metric from state 0 to each state after t+1 symbols
+    # suffix products (reversed scan of the transposed matrices), then the best metric from each state to any end state
+    S = _scan(M.flip(1).transpose(-1, -2)).flip(1).transpose(-1, -2)   # S[t] = M[t] x ... x M[T-1]
+    beta = torch.zeros(12, T + 1, 4, dtype=torch.float64, device=dev)
+    beta[:, :T, :] = S.amin(dim=-1)
+    state = (alpha + beta).argmin(dim=-1)                       # [12, T+1]: the ML path's state before symbol t
+    A, B = state >> 1, state & 1
+    z0 = A[:, :T]
+    z1 = A[:, 1:] ^ B[:, :T]                                    # x1 = A' ^ B
+    lo = 2 * z1 + z0
+    z2 = ((r - lo - 4).abs() < (r - lo).abs()).long()
+    v = 4 * z2 + lo
+    sliced = levels.round().clamp(0, 7).to(torch.uint8)      # segment / field syncs: nearest level (not decoded further)
+    return _from_per_encoder(v.to(torch.uint8), sliced, fields)

@@ -190,8 +190,10 @@ def test_full_size_batch_channel_independence(torch_cuda):
 def test_full_size_loopback_roundtrip(torch_cuda):
     """BASELINE config 4 per-GPU shard with 64 DISTINCT random streams x 64 fields: every channel's symbols are decoded
     back on the GPU by tests/loopback.py (independent demap / inverse precoder / de-interleave / RS syndromes /
-    de-randomize) and must give the TS that went in, with every RS codeword valid.  No oracle involved."""
-    from loopback import decode_symbols
+    de-randomize) and must give the TS that went in, with every RS codeword valid; every data symbol satisfies the
+    trellis code's parity check; and four fields of one channel, received with Gaussian noise that makes the plain slicer
+    err on about 8 % of the symbols, come back intact through the verifier's Viterbi decoder.  No oracle involved."""
+    from loopback import decode_symbols, trellis_violations, viterbi_symbols
     torch = torch_cuda
     C_, nf = 64, 64
     g = torch.Generator(device="cuda")
@@ -207,6 +209,15 @@ def test_full_size_loopback_roundtrip(torch_cuda):
         payload, worst = decode_symbols(d_sym[c * n:(c + 1) * n], nf)
         assert worst == 0, f"channel {c}: RS syndromes not zero"
         assert bool((payload == ts[c, :(nf - 1) * 312, 1:]).all()), f"channel {c}: decoded TS differs"
+        assert trellis_violations(d_sym[c * n:(c + 1) * n], nf) == 0, f"channel {c}: not a trellis code sequence"
+    c, k = 17, 4
+    clean = d_sym[c * n:c * n + k * FIELD_SYMBOLS]
+    g.manual_seed(9)
+    rx = clean.double() + 0.3 * torch.randn(clean.shape, generator=g, dtype=torch.float64, device="cuda")
+    assert int((rx.round().clamp(0, 7).to(torch.uint8) != clean).sum()) > 0.05 * clean.numel()
+    payload, worst = decode_symbols(viterbi_symbols(rx, k), k)
+    assert worst == 0
+    assert bool((payload == ts[c, :(k - 1) * 312, 1:]).all())
 
 
 def test_streaming_process_api(torch_cuda):

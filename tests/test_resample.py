@@ -161,3 +161,40 @@ def test_gpu_modulator_output_at_twice_the_rate():
     assert 10 * np.log10(inband / image) > 70.0
     q = _run(torch, atsc_amd.Resampler(1, 2, 1, K, out_format=atsc_amd.IQ_CS16), iq, [n]).view(np.int16)[0]
     assert np.array_equal(q.astype(np.float64), np.rint(np.clip(y.view(np.float32).astype(np.float64), -1, 1) * 32767))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("L", [2, 4])
+def test_gpu_decimated_output_is_the_modulator_output_at_64_fields(L):
+    """SURVEY 8f-1's check at BASELINE's batch length: 64 fields of two channels through the encoder and the Lx resampler on
+    the device; every L-th output sample is the encoder's own IQ (whose parity with the reference the oracle pins), bit for
+    bit, delayed by K/2 -- the part of the resampler's output that HAS a reference counterpart.  The other phases are
+    checked against the float64 model on the first and the last 20000 samples."""
+    import torch
+    nf, ch, K = 64, 2, 16
+    n = nf * FIELD_SYMBOLS
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    ts = torch.randint(0, 256, (ch, nf * 312, 188), dtype=torch.uint8, device="cuda", generator=g)
+    ts[:, :, 0] = 0x47
+    enc = atsc_amd.Encoder(channels=ch, max_fields=nf)
+    d_iq = torch.empty(ch, n, dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    enc.encode_batch(ts.data_ptr(), nf, None, d_iq.data_ptr(), st)
+    rs = atsc_amd.Resampler(ch, L, 1, K)
+    n_out = rs.out_count(n)
+    assert n_out == L * n
+    y = torch.empty(ch, n_out, dtype=torch.complex64, device="cuda")
+    rs.resample(d_iq.data_ptr(), n, n, y.data_ptr(), n_out, st)
+    torch.cuda.synchronize()
+    d = K // 2
+    same = torch.view_as_real(y[:, L * d::L]).view(torch.int32) == torch.view_as_real(d_iq[:, :n - d]).view(torch.int32)
+    assert bool(same.all())
+    h = model_taps(L, 1, K)
+    x0 = d_iq[0].cpu().numpy()
+    m = 20000
+    want = model_resample(x0[:m], L, 1, K, h, L * m)
+    assert np.abs(y[0, :L * m].cpu().numpy() - want).max() <= 2e-6
+    i0 = n - m                                        # the last m inputs, with K - 1 samples of history in front
+    want = model_resample(x0[i0 - (K - 1):], L, 1, K, h, L * (m + K - 1))[L * (K - 1):]
+    assert np.abs(y[0, L * i0:].cpu().numpy() - want).max() <= 2e-6
