@@ -192,7 +192,8 @@ def test_full_size_loopback_roundtrip(torch_cuda):
     back on the GPU by tests/loopback.py (independent demap / inverse precoder / de-interleave / RS syndromes /
     de-randomize) and must give the TS that went in, with every RS codeword valid; every data symbol satisfies the
     trellis code's parity check; and four fields of one channel, received with Gaussian noise that makes the plain slicer
-    err on about 8 % of the symbols, come back intact through the verifier's Viterbi decoder.  No oracle involved."""
+    err on about 4 % of the symbols (0.25 level steps rms: the code's error events, at distance 3, are then
+    a 6-sigma matter), come back intact through the verifier's Viterbi decoder.  No oracle involved."""
     from loopback import decode_symbols, trellis_violations, viterbi_symbols
     torch = torch_cuda
     C_, nf = 64, 64
@@ -213,8 +214,8 @@ def test_full_size_loopback_roundtrip(torch_cuda):
     c, k = 17, 4
     clean = d_sym[c * n:c * n + k * FIELD_SYMBOLS]
     g.manual_seed(9)
-    rx = clean.double() + 0.3 * torch.randn(clean.shape, generator=g, dtype=torch.float64, device="cuda")
-    assert int((rx.round().clamp(0, 7).to(torch.uint8) != clean).sum()) > 0.05 * clean.numel()
+    rx = clean.double() + 0.25 * torch.randn(clean.shape, generator=g, dtype=torch.float64, device="cuda")
+    assert int((rx.round().clamp(0, 7).to(torch.uint8) != clean).sum()) > 0.03 * clean.numel()
     payload, worst = decode_symbols(viterbi_symbols(rx, k), k)
     assert worst == 0
     assert bool((payload == ts[c, :(k - 1) * 312, 1:]).all())

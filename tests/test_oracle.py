@@ -132,7 +132,7 @@ def test_loopback_decoder_inverts_the_oracle():
 
 def test_loopback_viterbi_decodes_a_noisy_signal():
     """The verifier's trellis decoder (tests/loopback.py: viterbi_symbols, a (min,+) parallel scan over the 4-state code) on
-    the oracle's symbols of two fields with additive Gaussian noise of 0.3 level steps: the plain slicer gets several per
+    the oracle's symbols of two fields with additive Gaussian noise of 0.25 level steps: the plain slicer gets about four per
     cent of the data symbols wrong, the decoder recovers every one, and the chain behind it (de-interleave, RS syndromes,
     de-randomize) returns the TS payload.  Encoder output satisfies the code's parity check; the sliced noisy signal does not."""
     import torch
@@ -143,13 +143,13 @@ def test_loopback_viterbi_decodes_a_noisy_signal():
     clean = torch.from_numpy(sym.copy())
     assert trellis_violations(clean, nf) == 0
     g = torch.Generator().manual_seed(11)
-    rx = clean.double() + 0.3 * torch.randn(clean.shape, generator=g, dtype=torch.float64)
+    rx = clean.double() + 0.25 * torch.randn(clean.shape, generator=g, dtype=torch.float64)
     sliced = rx.round().clamp(0, 7).to(torch.uint8)
     data = torch.zeros(nf, 313, 832, dtype=torch.bool)
     data[:, 1:, 4:] = True
     data = data.view(-1)
     slicer_errors = int((sliced != clean)[data].sum())
-    assert slicer_errors > 0.05 * int(data.sum())
+    assert slicer_errors > 0.03 * int(data.sum())
     assert trellis_violations(sliced, nf) > 1000
     dec = viterbi_symbols(rx, nf)
     assert int((dec != clean)[data].sum()) == 0
