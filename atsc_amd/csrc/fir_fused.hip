@@ -11,8 +11,8 @@
 // i.e. a GEMM with M = 32 consecutive outputs, N = 32 columns = 16 channels x (re, im), K = 144 = nine K-steps of
 // v_mfma_f32_32x32x16_f16.  Both operands are split into two fp16 pieces (hi + lo, scaled into fp16's normal range):
 // the taps once on the host -- the A operand sits in registers for the whole kernel, nothing is regenerated per tile --
-// and z per element: level (exact in fp16) times T (fp32) by v_fma_mix, hi = f16(level * T), lo = f16(level * T - hi), 3
-// vector instructions per element including the byte -> level conversion.  Y = Ahi Zhi + Alo Zhi + Ahi Zlo with fp32
+// and z per element: level (exact in fp16) times the oscillator, which k_osc_table hands over already split into two fp16
+// pieces, in three packed fp16 instructions per PAIR of elements (mix_pair below).  Y = Ahi Zhi + Alo Zhi + Ahi Zlo with fp32
 // accumulation carries >= 21 significant bits of every product (the dropped Alo Zlo term is 2^-22 relative).
 // A tile advances by 32 outputs = two K-steps, so the B operand (Z) is a sliding window of nine K-step slots in
 // registers: a tile converts only its 32 newest inputs per column, the rest is a renaming (the tile loop is unrolled
@@ -26,8 +26,9 @@
 //     precoder / trellis / mapper / sync producer from the interleaved bytes (reference: trellis.h:10-51,
 //     field_sync.h:12-26; 0.25 B per symbol from HBM, the symbols never exist in HBM).  Not FUSED: coalesced 16-byte
 //     loads of the u8 symbols that k_trellis_map wrote, three tiles ahead.
-//   * the oscillator reaches it as one float per lane and tile (32 positions x re/im), three tiles ahead, through a
-//     288-byte LDS window; the batch table T_f comes from k_osc_table (re / im planes).
+//   * the oscillator reaches it as one dword per lane and tile (32 positions x re/im), a whole round of nine tiles at a
+//     time, through LDS windows double-buffered by round parity; the batch table T_f comes from k_osc_table (re / im
+//     planes of split entries).
 //   * C (32x32 fp32) goes through a wave-private LDS image [channel][32 outputs] in the OUTPUT sample format and leaves
 //     as whole 128-byte lines, 16 bytes per lane, spread over the next tile's MFMA sequence.
 // No workgroup barriers; waves are independent (LDS operations of a wave execute in program order).
