@@ -101,15 +101,18 @@ def test_config3_64_field_iq(torch_cuda, golden):
     """BASELINE config 3: full chain IQ on 64 fields within 1e-5 of full scale (oscillator recursion tracked)."""
     nf = 64
     ts = ts_mt(1234, nf)
+    # the compiled reference itself where oracle/_ref travelled with the tree, else the restatement (which the golden
+    # vectors pin to the reference): either way the 64-field public-API hash of golden.json is checked first, so the
+    # "expected" side is the reference's output, and the test says which checker produced it
     if ref_available():
-        want = Ref().process_fields(ts, nf, want=("iq",))["iq"]
+        which, want = "compiled reference (oracle/_ref)", Ref().process_fields(ts, nf, want=("iq",))["iq"]
     else:
-        want = Oracle().process_fields(ts, nf, want=("iq",))["iq"]
+        which, want = "C restatement (oracle/atsc_oracle.c)", Oracle().process_fields(ts, nf, want=("iq",))["iq"]
     enc = atsc_amd.Encoder(channels=1, max_fields=nf)
     _, iq = run_device(torch_cuda, enc, ts, 1, nf)
     err = np.abs(iq.view(np.float32) - want)
-    print(f"64-field IQ: max abs err {err.max():.3e}, last field {err[-2 * FIELD_SYMBOLS:].max():.3e}")
-    assert err.max() <= IQ_TOL
+    print(f"64-field IQ against the {which}: max abs err {err.max():.3e}, last field {err[-2 * FIELD_SYMBOLS:].max():.3e}")
+    assert err.max() <= IQ_TOL, which
 
 
 def test_multichannel_and_batch_split(torch_cuda):
@@ -382,13 +385,14 @@ def _quantize(iq_f32, full):
     return np.rint(np.clip(iq_f32.astype(np.float64), -1.0, 1.0) * full)
 
 
+@pytest.mark.parametrize("C_,nf", [(3, 2), (11, 1)])
 @pytest.mark.parametrize("fmt,dt,full", [(atsc_amd.IQ_CS16, np.int16, 32767.0), (atsc_amd.IQ_CS8, np.int8, 127.0)])
-def test_sdr_sample_formats(torch_cuda, fmt, dt, full):
+def test_sdr_sample_formats(torch_cuda, fmt, dt, full, C_, nf):
     """CS16 / CS8 device output == the formula applied to the CF32 output of the same encode, bit for bit; and within
     one LSB (+ the 1e-5 float tolerance) of the oracle's IQ.  3 channels so that a full pair and an odd pair (dummy
-    stream into the trash rows) are covered; 2 fields so that the short last FFT block of a field is followed by data."""
+    stream into the trash rows) are covered; 2 fields so that the short last FFT block of a field is followed by data; 11
+    channels (AUTO still picks the FFT form) for a full group of 8 plus a partly filled one."""
     torch = torch_cuda
-    C_, nf = 3, 2
     per = [ts_mix(300 + c, nf) for c in range(C_)]
     ts = np.concatenate(per)
     _, iq = run_device(torch, atsc_amd.Encoder(channels=C_, max_fields=nf), ts, C_, nf)
