@@ -35,7 +35,7 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
            "atsc_hip_encode_begin", "atsc_hip_encode_finish",
            "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_mix_fir_static", "atsc_hip_export_state", "atsc_hip_import_state",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
-           "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form",
+           "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form", "atsc_hip_set_upsample", "atsc_hip_get_upsample",
            "atsc_hip_process_chunked",
            "atsc_hip_error_string", "atsc_hip_version",
            # include/atsc_hip_resample.h
@@ -114,6 +114,8 @@ def load_library():
     L.atsc_hip_set_iq_format.argtypes = [vp, C.c_int]
     L.atsc_hip_set_fir_form.argtypes = [vp, C.c_int]
     L.atsc_hip_get_fir_form.argtypes = [vp]
+    L.atsc_hip_set_upsample.argtypes = [vp, C.c_int]
+    L.atsc_hip_get_upsample.argtypes = [vp]
     L.atsc_hip_iq_sample_bytes.argtypes = [C.c_int]
     L.atsc_hip_iq_sample_bytes.restype = C.c_size_t
     L.atsc_hip_process_chunked.argtypes = [vp, u8p, C.c_uint, C.c_size_t, CHUNK_CB, vp]
@@ -208,6 +210,13 @@ class Encoder:
             check(form)
         return form
 
+    def set_upsample(self, factor):
+        """1 (default) or 2: output samples per symbol (include/atsc_hip.h, atsc_hip_set_upsample)."""
+        check(self.L.atsc_hip_set_upsample(self.h, factor))
+
+    def upsample(self):
+        return self.L.atsc_hip_get_upsample(self.h)
+
     # ---- batched device path
     def encode_batch(self, d_ts, fields, d_sym=None, d_iq=None, stream=None):
         check(self.L.atsc_hip_encode_batch(self.h, d_ts, fields, d_sym, d_iq, stream))
@@ -226,7 +235,7 @@ class Encoder:
         ts = np.ascontiguousarray(ts, np.uint8)
         assert ts.size == self.channels * fields * FIELD_TS_BYTES
         sym = np.empty(self.channels * fields * FIELD_SYMBOLS, np.uint8) if want_sym else None
-        iq = np.empty(self.channels * fields * FIELD_SYMBOLS, np.complex64) if want_iq else None
+        iq = np.empty(self.channels * fields * FIELD_SYMBOLS * self.upsample(), np.complex64) if want_iq else None
         check(self.L.atsc_hip_encode_batch_host(self.h, ts.ctypes.data, fields, sym.ctypes.data if want_sym else None,
                                                 iq.ctypes.data if want_iq else None))
         return sym, iq
@@ -280,7 +289,7 @@ def get_table(which, handle=None):
     """Constant tables as the library builds them (no GPU needed when handle is None)."""
     import numpy as np
     shapes = {0: (112, np.float32), 1: (PADDED_SYMBOLS * 2, np.float32), 2: (2, np.float32),
-              3: (187 * 312, np.uint8), 4: (820, np.uint8), 5: (820, np.uint8), 6: (21, np.uint8)}
+              3: (187 * 312, np.uint8), 4: (820, np.uint8), 5: (820, np.uint8), 6: (21, np.uint8), 7: (112, np.float32)}
     n, dt = shapes[which]
     out = np.zeros(n, dt)
     check(load_library().atsc_hip_get_table(handle, which, out.ctypes.data, out.nbytes))

@@ -44,6 +44,7 @@ struct atsc_hip_encoder {
     bool sym_internal = false; // the last batch wrote its symbols to the internal buffer (no caller buffer, not the fused form)
     int iq_format = ATSC_HIP_IQ_CF32;
     int fir_form = ATSC_HIP_FIR_AUTO;
+    int upsample = 1;          // output samples per symbol (atsc_hip_set_upsample)
     void* d_tables = nullptr;
 
     // streaming path (1 channel): two slots so that the upload and the kernels of batch k+1 run while the IQ of batch k
@@ -175,7 +176,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     e->dtab.prbs = tb + off_pr;
     e->dtab.prbs_rows = tb + off_prr;
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
-    TRY_OR_FREE(upload_mm_tables(e->tab.taps));
+    TRY_OR_FREE(upload_mm_tables(e->tab.taps, e->tab.taps_half));
 
     // per-channel working buffers
     e->buf.max_fields = cfg->max_fields;
@@ -278,14 +279,15 @@ int run_back(atsc_hip_encoder* e, const uint4* carry_xor, int fields, uint8_t* d
 // The matrix-core kernels address a group of 16 channel rows through one buffer descriptor with 32-bit offsets: 16 rows of
 // the largest batch's IQ (max_fields x 260416 samples) must stay below 4 GiB -- 128 fields of complex64, 257 of CS16.  A
 // property of the handle (not of a batch), so that equal handles pick equal forms.
-bool matrix_forms_fit(const atsc_hip_encoder* e, int iq_format) {
-    const uint64_t row_bytes = (uint64_t)e->cfg.max_fields * kFieldSyms * atsc_hip_iq_sample_bytes(iq_format);
+bool matrix_forms_fit(const atsc_hip_encoder* e, int iq_format, int upsample) {
+    const uint64_t row_bytes = (uint64_t)e->cfg.max_fields * kFieldSyms * upsample * atsc_hip_iq_sample_bytes(iq_format);
     return 16 * row_bytes <= 0xffffffffull;
 }
 
 int resolve_fir_form(const atsc_hip_encoder* e) {
     if (e->fir_form != ATSC_HIP_FIR_AUTO) return e->fir_form;
-    if (!matrix_forms_fit(e, e->iq_format)) return ATSC_HIP_FIR_FFT;
+    if (e->upsample != 1) return ATSC_HIP_FIR_FUSED;   // only the matrix-core kernel interpolates (set_upsample checked that it fits)
+    if (!matrix_forms_fit(e, e->iq_format, 1)) return ATSC_HIP_FIR_FFT;
     // The fused kernel works on groups of kFusedGroup channels and costs the same for a partly filled group, the FFT
     // form costs per channel: fused when at least 80 % of the matrix columns carry a channel.
     const int groups = (e->cfg.channels + kFusedGroup - 1) / kFusedGroup;
@@ -300,12 +302,14 @@ int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, vo
     float2* oout = e->d_osc[e->osc_cur ^ 1];
     if (d_iq) {
         const int form = resolve_fir_form(e);
-        const bool mfma = form == ATSC_HIP_FIR_MFMA;   // (the fused form does not come through here)
+        // (the fused form does not come through here, except for atsc_hip_mix_fir on a 2x handle: caller-supplied symbols
+        // then take the matrix-core kernel's unfused instance, the only other one that interpolates)
+        const bool mfma = form == ATSC_HIP_FIR_MFMA || e->upsample != 1;
         launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields, mfma);
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
         if (mfma)
-            launch_mix_fir_mfma(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms,
-                                reinterpret_cast<const float*>(e->d_osc_tab), C, fields, e->iq_format);
+            launch_mix_fir_mfma(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms * e->upsample,
+                                reinterpret_cast<const float*>(e->d_osc_tab), C, fields, e->iq_format, e->upsample);
         else
             launch_mix_fir_fft(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms, e->d_osc_tab, C, fields, e->iq_format);
     } else {
@@ -359,9 +363,9 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
         launch_osc_table(s, e->d_osc[e->osc_cur], e->d_osc[e->osc_cur ^ 1], e->d_osc_tab, e->scale, fields, true);
         e->osc_cur ^= 1;
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
-        launch_mix_fir_fused(s, e->dtab, e->buf, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms,
+        launch_mix_fir_fused(s, e->dtab, e->buf, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms * e->upsample,
                              reinterpret_cast<const float*>(e->d_osc_tab), e->cfg.channels, fields, e->field_index,
-                             e->iq_format);
+                             e->iq_format, e->upsample);
         rc = static_cast<int>(hipGetLastError());
         if (rc) return rc;
         e->sym_internal = false;
@@ -431,11 +435,11 @@ extern "C" int atsc_hip_encode_batch_host(atsc_hip_encoder* e, const uint8_t* h_
     int rc = static_cast<int>(hipMalloc(&d_ts, ts_bytes));
     if (!rc) rc = static_cast<int>(hipMemcpy(d_ts, h_ts, ts_bytes, hipMemcpyHostToDevice));
     if (!rc && h_sym) rc = static_cast<int>(hipMalloc(&d_sym, sym_bytes));
-    if (!rc && h_iq) rc = static_cast<int>(hipMalloc(&d_iq, sym_bytes * ss));
+    if (!rc && h_iq) rc = static_cast<int>(hipMalloc(&d_iq, sym_bytes * ss * e->upsample));
     if (!rc) rc = atsc_hip_encode_batch(e, d_ts, fields, d_sym, d_iq, nullptr);
     if (!rc) rc = static_cast<int>(hipDeviceSynchronize());
     if (!rc && h_sym) rc = static_cast<int>(hipMemcpy(h_sym, d_sym, sym_bytes, hipMemcpyDeviceToHost));
-    if (!rc && h_iq) rc = static_cast<int>(hipMemcpy(h_iq, d_iq, sym_bytes * ss, hipMemcpyDeviceToHost));
+    if (!rc && h_iq) rc = static_cast<int>(hipMemcpy(h_iq, d_iq, sym_bytes * ss * e->upsample, hipMemcpyDeviceToHost));
     hipFree(d_ts);
     hipFree(d_sym);
     hipFree(d_iq);
@@ -454,7 +458,8 @@ extern "C" size_t atsc_hip_iq_sample_bytes(int format) {
 extern "C" int atsc_hip_set_fir_form(atsc_hip_encoder* e, int form) {
     if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_FUSED) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
-    if ((form == ATSC_HIP_FIR_MFMA || form == ATSC_HIP_FIR_FUSED) && !matrix_forms_fit(e, e->iq_format)) return ATSC_HIP_ERR_TOO_LARGE;
+    if ((form == ATSC_HIP_FIR_MFMA || form == ATSC_HIP_FIR_FUSED) && !matrix_forms_fit(e, e->iq_format, e->upsample)) return ATSC_HIP_ERR_TOO_LARGE;
+    if (form == ATSC_HIP_FIR_FFT && e->upsample != 1) return ATSC_HIP_ERR_ARG;   // the FFT form does not interpolate
     e->fir_form = form;
     return ATSC_HIP_OK;
 }
@@ -467,10 +472,32 @@ extern "C" int atsc_hip_get_fir_form(atsc_hip_encoder* e) {
 extern "C" int atsc_hip_set_iq_format(atsc_hip_encoder* e, int format) {
     if (!e || !atsc_hip_iq_sample_bytes(format)) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
-    if ((e->fir_form == ATSC_HIP_FIR_MFMA || e->fir_form == ATSC_HIP_FIR_FUSED) && !matrix_forms_fit(e, format)) return ATSC_HIP_ERR_TOO_LARGE;
+    if ((e->fir_form == ATSC_HIP_FIR_MFMA || e->fir_form == ATSC_HIP_FIR_FUSED || e->upsample != 1) && !matrix_forms_fit(e, format, e->upsample))
+        return ATSC_HIP_ERR_TOO_LARGE;
     e->iq_format = format;
     return ATSC_HIP_OK;
 }
+
+extern "C" int atsc_hip_set_upsample(atsc_hip_encoder* e, int factor) {
+    if (!e || (factor != 1 && factor != 2)) return ATSC_HIP_ERR_ARG;
+    if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if (factor == e->upsample) return ATSC_HIP_OK;
+    if (factor == 2) {
+        if (e->fir_form == ATSC_HIP_FIR_FFT) return ATSC_HIP_ERR_ARG;
+        if (!matrix_forms_fit(e, e->iq_format, 2)) return ATSC_HIP_ERR_TOO_LARGE;
+    }
+    e->upsample = factor;
+    // the streaming slots are sized for the output rate: released here, allocated again by the next atsc_hip_process call
+    for (auto& sl : e->slot) {
+        hipFree(sl.d_iq);
+        sl.d_iq = nullptr;
+        if (sl.h_iq) hipHostFree(sl.h_iq);
+        sl.h_iq = nullptr;
+    }
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_get_upsample(atsc_hip_encoder* e) { return e ? e->upsample : ATSC_HIP_ERR_ARG; }
 
 // Streaming path: reference semantics of atsc_encoder_impl::process (atsc.cpp:59-77).  With mtu_samples > 0 every
 // field is handed out in pieces of at most mtu_samples, never spanning a field (util/atsc_encoder.cpp:90-99).
@@ -488,9 +515,9 @@ int streaming_setup(atsc_hip_encoder* e) {
     // sized for CF32 (the largest sample format); each piece is retried if an earlier call ran out of memory
     for (auto& sl : e->slot) {
         if (!sl.d_ts) HIP_TRY(hipMalloc(&sl.d_ts, F * kFieldTs));
-        if (!sl.d_iq) HIP_TRY(hipMalloc(&sl.d_iq, F * kFieldSyms * sizeof(float2)));
+        if (!sl.d_iq) HIP_TRY(hipMalloc(&sl.d_iq, F * kFieldSyms * e->upsample * sizeof(float2)));
         if (!sl.h_ts) HIP_TRY(hipHostMalloc(&sl.h_ts, F * kFieldTs, hipHostMallocDefault));
-        if (!sl.h_iq) HIP_TRY(hipHostMalloc(&sl.h_iq, F * kFieldSyms * sizeof(float2), hipHostMallocDefault));
+        if (!sl.h_iq) HIP_TRY(hipHostMalloc(&sl.h_iq, F * kFieldSyms * e->upsample * sizeof(float2), hipHostMallocDefault));
         if (!sl.encoded) HIP_TRY(hipEventCreateWithFlags(&sl.encoded, hipEventDisableTiming));
         if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     }
@@ -520,7 +547,8 @@ static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned cou
     if (rc) return rc;
     const size_t F = e->cfg.max_fields;
     const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
-    const size_t field_bytes = (size_t)kFieldSyms * ss;
+    const size_t field_samples = (size_t)kFieldSyms * e->upsample;
+    const size_t field_bytes = field_samples * ss;
     // copy-before-return contract (atsc.cpp:66); no exception may cross the C boundary
     try {
         e->pending.insert(e->pending.end(), h_pkts, h_pkts + (size_t)count * ATSC_HIP_TS_PACKET_BYTES);
@@ -560,10 +588,10 @@ static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned cou
             uint8_t* field = sl.h_iq + (size_t)f * field_bytes;
             if (cb) cb(user, field, (unsigned)field_bytes);
             if (chunk_cb) {
-                size_t remaining = kFieldSyms;
+                size_t remaining = field_samples;
                 while (remaining > 0) {
                     const size_t n = std::min(remaining, mtu_samples);
-                    chunk_cb(user, field + ((size_t)kFieldSyms - remaining) * ss, n, e->iq_format);
+                    chunk_cb(user, field + (field_samples - remaining) * ss, n, e->iq_format);
                     remaining -= n;
                 }
             }
@@ -723,6 +751,7 @@ extern "C" int atsc_hip_get_table(atsc_hip_encoder* e, int which, void* h_out, s
         case 4: src = t->fsync[0].data(); n = 820; break;
         case 5: src = t->fsync[1].data(); n = 820; break;
         case 6: src = t->rs_gen; n = 21; break;
+        case 7: src = t->taps_half; n = sizeof(float) * kTaps; break;
         default: return ATSC_HIP_ERR_ARG;
     }
     if (bytes < n) return ATSC_HIP_ERR_ARG;

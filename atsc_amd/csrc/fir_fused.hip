@@ -65,12 +65,13 @@ static_assert(kTile + 110 <= 16 * kKSteps, "K must cover the filter");
 static_assert(kRound % kAhead == 0 && (2 * kRound) % kKSteps == 0, "static register renaming");
 static_assert(kFusedGroup == 16, "one wave task = 16 channels");
 
-// A operand: [hi | lo][K-step][lane] x 16 bytes, in the MFMA lane layout (lane = output row p + 32 * half, 8 consecutive k)
-__device__ uint4 g_a_tab[2 * kKSteps * 64];
+// A operand: [phase][hi | lo][K-step][lane] x 16 bytes, in the MFMA lane layout (lane = output row p + 32 * half, 8
+// consecutive k).  Phase 0: the reference's taps; phase 1: the same pulse half a symbol later (2x output, see UP below)
+__device__ uint4 g_a_tab[2 * 2 * kKSteps * 64];
 
-template <int FMT> struct Geo {
+template <int FMT, int UP> struct Geo {
     typedef typename OutSample<FMT>::type out_t;
-    static constexpr int kRowBytes = kTile * (int)sizeof(out_t);   // one channel's samples of a tile: 256 / 128 / 64 B
+    static constexpr int kRowBytes = kTile * UP * (int)sizeof(out_t);   // one channel's samples of a tile: 256 / 128 / 64 B x UP
     static constexpr int kImgRow = kRowBytes + 16;                   // LDS image row (16-byte aligned, rows on different banks)
     static constexpr int kPieces = kRowBytes / 16;                   // 16-byte pieces per row
     static constexpr int kRowsPerStore = 64 / kPieces;               // channel rows one store instruction covers: 4 / 8 / 16
@@ -170,9 +171,16 @@ struct FirArgs {
 
 }  // namespace
 
-template <int FMT, bool FUSED>
-__global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) {
-    typedef Geo<FMT> G;
+// UP = 2: the upsampling form of the filter ("upsampling to the SDR rate").  The same pulse evaluated at half-symbol
+// offsets is a second Toeplitz operand A1 on the SAME Z window (112 taps centred between taps 55 and 56 fit the 144 inputs):
+//   y2[2 i] = sum_k taps[k] z[i + k]   (the reference's sample, bit for bit the UP = 1 output)
+//   y2[2 i + 1] = sum_k taps_half[k] z[i + k]
+// i.e. a polyphase interpolator by 2 whose phase 0 is the reference filter; one pass over the symbols, no 1x IQ in HBM.  54
+// MFMAs per tile on two accumulators, the Z operand is converted once; both A operands stay in registers, so one wave per
+// SIMD (and the kernel becomes matrix-pipe- and store-bound: twice the products, twice the bytes).
+template <int FMT, bool FUSED, int UP>
+__global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(const FirArgs a) {
+    typedef Geo<FMT, UP> G;
     typedef typename G::out_t out_t;
     __shared__ __align__(16) uint8_t s_ring[kWaves][kFusedGroup * kRingRow];
     __shared__ __align__(16) uint8_t s_img[kWaves][kFusedGroup * G::kImgRow];
@@ -194,19 +202,21 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
     const int ch = cg * kFusedGroup + min(cl, rows_valid - 1);                // rows past the end repeat the last one; never stored
 
     // ---- A operand: the Toeplitz tap matrix, constant, in registers (read from LDS per K-step it cost 0.2 ms per launch)
-    h8 ahi[kKSteps], alo[kKSteps];
+    h8 ahi[UP][kKSteps], alo[UP][kKSteps];
 #pragma unroll
-    for (int ks = 0; ks < kKSteps; ++ks) {
-        ahi[ks] = __builtin_bit_cast(h8, g_a_tab[ks * 64 + lane]);
-        alo[ks] = __builtin_bit_cast(h8, g_a_tab[(kKSteps + ks) * 64 + lane]);
-    }
+    for (int ph = 0; ph < UP; ++ph)
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) {
+            ahi[ph][ks] = __builtin_bit_cast(h8, g_a_tab[((2 * ph) * kKSteps + ks) * 64 + lane]);
+            alo[ph][ks] = __builtin_bit_cast(h8, g_a_tab[((2 * ph + 1) * kKSteps + ks) * 64 + lane]);
+        }
 
     // ---- memory: buffer descriptors with a wave-uniform base, a per-lane 32-bit offset and a scalar per-tile offset, so
     // that no vector instruction is spent on addresses; stores to rows or tiles that do not exist are dropped by the
     // range check (rows past the end lie behind num_records; for a tile that does not exist num_records is made 0)
     constexpr int kRsrcFlags = 0x00020000;   // raw buffer, 32-bit data format
     const uint32_t iq_row_bytes = (uint32_t)(a.iq_stride * sizeof(out_t));
-    uint8_t* iq_base = reinterpret_cast<uint8_t*>(a.iq) + ((size_t)cg * kFusedGroup * a.iq_stride + (size_t)f * kFieldSyms) * sizeof(out_t);
+    uint8_t* iq_base = reinterpret_cast<uint8_t*>(a.iq) + ((size_t)cg * kFusedGroup * a.iq_stride + (size_t)f * kFieldSyms * UP) * sizeof(out_t);
     const int iq_records = (int)((uint32_t)rows_valid * iq_row_bytes);
     const int st_piece = lane % G::kPieces, st_row = lane / G::kPieces;
     const uint32_t st_off = (uint32_t)st_row * iq_row_bytes + 16u * st_piece;               // + q * kRowsPerStore rows
@@ -475,10 +485,12 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
     float ofn[3];
 #pragma unroll
     for (int j = 0; j < kRound; ++j) osc_wr[64 * j] = osc_fetch(tile0 + 1 + j);
-    f16v acc_prev;
+    f16v zero16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc_prev[e] = 0.f;
-    const f16v zero16 = acc_prev;
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
+    f16v acc_prev[UP];
+#pragma unroll
+    for (int ph = 0; ph < UP; ++ph) acc_prev[ph] = zero16;
 
     for (int r = 0; r < a.rounds; ++r) {
         const int Tg = tile0 + kRound * r;
@@ -504,11 +516,19 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
             const bool prev_ok = (u > 0 || r > 0) && tile - 1 < kTiles;
             const __amdgpu_buffer_rsrc_t rs_iq = __builtin_amdgcn_make_buffer_rsrc(iq_base, 0, prev_ok ? iq_records : 0, kRsrcFlags);
             const int st_soff = (tile - 1) * G::kRowBytes;
-            float y[16];
+            // chain slots of the tile's side work (UP = 1: the numbers the comments of side() name)
+            constexpr int kChain = 27 * UP;              // MFMAs per tile
+            constexpr int kMixAt = 6 * UP;               // K-steps 0 and 1 have issued: their slots take the next tile's
+            constexpr int kImgAt = kMixAt + 8;           // image writes, 4 values per slot
+            constexpr int kRdAt = kImgAt + 4 * UP;       // image reads, then the stores two slots behind
+            static_assert(kRdAt + 2 + G::kStores <= kChain, "side work fits the chain");
+            float y[16 * UP];
             uint2 sy[2];
             uint4 tw[4];
             uint4 piece[G::kStores];
-            f16v acc = zero16;
+            f16v acc[UP];
+#pragma unroll
+            for (int ph = 0; ph < UP; ++ph) acc[ph] = zero16;
             auto side = [&](int i) {
                 if (i == 0) {
                     if (u % 3 == 0) {
@@ -520,10 +540,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                         ps[(u + 1) % kAhead] = sym_fetch(tile + 1 + kAhead);
                     }
                 }
-                if (i >= 1 && i <= 4) {
+                if (i >= 1 && i <= 4 * UP) {
                     constexpr float inv = 1.0f / (kAScale * kZScale);
 #pragma unroll
-                    for (int e = 4 * (i - 1); e < 4 * i; ++e) y[e] = acc_prev[e] * inv;
+                    for (int e = 4 * (i - 1); e < 4 * i; ++e) y[e] = acc_prev[e >> 4][e & 15] * inv;
                 }
                 if (i == 2) {
 #pragma unroll
@@ -533,10 +553,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                         tw[2 * s + 1] = *reinterpret_cast<const uint4*>(osc_rd + obuf + 64 * u + 16 * s + 4);
                     }
                 }
-                if (i >= 6 && i <= 9) {
+                if (i >= kMixAt && i < kMixAt + 4) {
                     // four elements (one ring dword) of the next tile's newest K-steps, into the slots of this tile's K-steps
                     // 0 and 1, whose MFMAs have issued
-                    const int c4 = i - 6, s = c4 >> 1, d = c4 & 1;
+                    const int c4 = i - kMixAt, s = c4 >> 1, d = c4 & 1;
                     const int slot = (2 * u + s) % kKSteps;
                     const uint32_t dw = d ? sy[s].y : sy[s].x;
                     const uint4 t = tw[2 * s + d];
@@ -545,13 +565,14 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                     if (d == 0) { bhi[slot].x = h0; bhi[slot].y = h1; blo[slot].x = l0; blo[slot].y = l1; }
                     else        { bhi[slot].z = h0; bhi[slot].w = h1; blo[slot].z = l0; blo[slot].w = l1; }
                 }
-                if (i >= 14 && i <= 17) {
-                    // C -> line image: register e of lane (n, h) is output row (e & 3) + 8 (e >> 2) + 4 h of column n
+                if (i >= kImgAt && i < kImgAt + 4 * UP) {
+                    // C -> line image: register e of lane (n, h) is output row (e & 3) + 8 (e >> 2) + 4 h of column n; with UP = 2
+                    // the two phases interleave (sample 2 row + phase)
 #pragma unroll
-                    for (int e = 4 * (i - 14); e < 4 * (i - 13); ++e)
-                        put_component<FMT>(img_wr, (e & 3) + 8 * (e >> 2) + 4 * h, comp, y[e]);
+                    for (int e = 4 * (i - kImgAt); e < 4 * (i - kImgAt + 1); ++e)
+                        put_component<FMT>(img_wr, UP * ((e & 3) + 8 * ((e & 15) >> 2) + 4 * h) + (e >> 4), comp, y[e]);
                 }
-                if (u % 3 == 2 && i == 26) {
+                if (u % 3 == 2 && i == kChain - 1) {
                     // the group fetched at tile u - 2 goes to the other buffer; at the round's end the producer's interleaved
                     // bytes are claimed as well, where the wait is still an exact count
 #pragma unroll
@@ -560,10 +581,10 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
                         if (u == kRound - 1) asm volatile("" ::"v"(pa0), "v"(pa1), "v"(pa2), "v"(pb0), "v"(pb1), "v"(pb2));
                     }
                 }
-                if (i >= 18 && i < 18 + G::kStores)
-                    piece[i - 18] = *reinterpret_cast<const uint4*>(img_rd + (i - 18) * G::kRowsPerStore * G::kImgRow);
-                if (i >= 20 && i < 20 + G::kStores) {
-                    const int q = i - 20;
+                if (i >= kRdAt && i < kRdAt + G::kStores)
+                    piece[i - kRdAt] = *reinterpret_cast<const uint4*>(img_rd + (i - kRdAt) * G::kRowsPerStore * G::kImgRow);
+                if (i >= kRdAt + 2 && i < kRdAt + 2 + G::kStores) {
+                    const int q = i - (kRdAt + 2);
                     const uint4 v = piece[q];
                     // non-temporal: the IQ is written once and never read back by the GPU
                     __builtin_amdgcn_raw_buffer_store_b128((v4u){v.x, v.y, v.z, v.w}, rs_iq, (int)(st_off + q * st_step), st_soff, 2);
@@ -574,15 +595,20 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
             for (int ks = 0; ks < kKSteps; ++ks) {
                 const int slot = (2 * u + ks) % kKSteps;
                 const h8 bh = __builtin_bit_cast(h8, bhi[slot]), bl = __builtin_bit_cast(h8, blo[slot]);
-                const h8 ah = ahi[ks], al = alo[ks];
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-                side(3 * ks);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-                side(3 * ks + 1);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-                side(3 * ks + 2);
+#pragma unroll
+                for (int ph = 0; ph < UP; ++ph) {
+                    const h8 ah = ahi[ph][ks], al = alo[ph][ks];
+                    const int i0 = 3 * (UP * ks + ph);
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ph], 0, 0, 0);
+                    side(i0);
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph], 0, 0, 0);
+                    side(i0 + 1);
+                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph], 0, 0, 0);
+                    side(i0 + 2);
+                }
             }
-            acc_prev = acc;
+#pragma unroll
+            for (int ph = 0; ph < UP; ++ph) acc_prev[ph] = acc[ph];
         }
         if constexpr (FUSED) {
             // the ring moves on to what the next round reads (nothing is needed behind the run's last tile unless the tap wants it)
@@ -605,7 +631,8 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
         const __amdgpu_buffer_rsrc_t rs_iq = __builtin_amdgcn_make_buffer_rsrc(iq_base, 0, tile < kTiles ? iq_records : 0, kRsrcFlags);
         constexpr float inv = 1.0f / (kAScale * kZScale);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) put_component<FMT>(img_wr, (e & 3) + 8 * (e >> 2) + 4 * h, comp, acc_prev[e] * inv);
+        for (int e = 0; e < 16 * UP; ++e)
+            put_component<FMT>(img_wr, UP * ((e & 3) + 8 * ((e & 15) >> 2) + 4 * h) + (e >> 4), comp, acc_prev[e >> 4][e & 15] * inv);
         lds_order();
 #pragma unroll
         for (int q = 0; q < G::kStores; ++q) {
@@ -615,62 +642,72 @@ __global__ __launch_bounds__(64 * kWaves, 2) void k_mix_fir_mm(const FirArgs a) 
     }
 }
 
-hipError_t upload_mm_tables(const float* taps112) {
-    std::vector<uint16_t> h(2 * kKSteps * 64 * 8);
-    for (int ks = 0; ks < kKSteps; ++ks)
-        for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 8; ++j) {
-                const int p = lane & 31, hh = lane >> 5;
-                const int idx = 16 * ks + 8 * hh + j - p;
-                const float v = (idx >= 0 && idx <= 110) ? taps112[idx] * kAScale : 0.0f;
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)(v - (float)hi);
-                h[((size_t)ks * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, hi);
-                h[((size_t)(kKSteps + ks) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, lo);
-            }
+hipError_t upload_mm_tables(const float* taps112, const float* taps_half112) {
+    std::vector<uint16_t> h(2 * 2 * kKSteps * 64 * 8);
+    for (int ph = 0; ph < 2; ++ph)
+        for (int ks = 0; ks < kKSteps; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int p = lane & 31, hh = lane >> 5;
+                    const int idx = 16 * ks + 8 * hh + j - p;
+                    // phase 0: 111 taps; phase 1: 112 taps, centred half a symbol later
+                    const float v = ph == 0 ? ((idx >= 0 && idx <= 110) ? taps112[idx] * kAScale : 0.0f)
+                                            : ((idx >= 0 && idx <= 111) ? taps_half112[idx] * kAScale : 0.0f);
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    h[((size_t)((2 * ph) * kKSteps + ks) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, hi);
+                    h[((size_t)((2 * ph + 1) * kKSteps + ks) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, lo);
+                }
     return hipMemcpyToSymbol(HIP_SYMBOL(g_a_tab), h.data(), sizeof(uint16_t) * h.size());
 }
 
 namespace {
 
-// Runs: long runs amortise what a run pays at its start; short runs balance the grid.  The chip holds 2048 of these waves
-// at once (2 per SIMD), so a launch takes about ceil(tasks / 2048) waves of (run length + start-up) tile times.
-int pick_rounds(int ch_groups, int fields, int startup_tiles) {
+// Runs: long runs amortise what a run pays at its start; short runs balance the grid.  The chip holds `resident` of these
+// waves at once (2048 = 2 per SIMD; 1024 for the 2x form), so a launch takes about ceil(tasks / resident) waves of (run
+// length + start-up) tile times.
+int pick_rounds(int ch_groups, int fields, int startup_tiles, int resident) {
     const int max_rounds = (kTiles + kRound - 1) / kRound;   // 905: one run per field
     long best = -1;
     int rounds = max_rounds;
     for (int runs = 1; runs <= 64; ++runs) {
         const int cand = (max_rounds + runs - 1) / runs;
         const long t = (long)((kTiles + kRound * cand - 1) / (kRound * cand)) * ch_groups * fields;
-        const long cost = ((t + 2047) / 2048) * (kRound * cand + startup_tiles);
+        const long cost = ((t + resident - 1) / resident) * (kRound * cand + startup_tiles);
         if (best < 0 || cost < best) { best = cost; rounds = cand; }
     }
     return rounds;
 }
 
-template <int FMT, bool FUSED>
+template <int FMT, bool FUSED, int UP>
 void launch_mm(hipStream_t s, FirArgs a) {
     a.ch_groups = (a.channels + kFusedGroup - 1) / kFusedGroup;
-    a.rounds = pick_rounds(a.ch_groups, a.fields, FUSED ? 12 : 4);
+    a.rounds = pick_rounds(a.ch_groups, a.fields, FUSED ? 12 : 4, UP == 1 ? 2048 : 1024);
     a.runs_per_field = (kTiles + kRound * a.rounds - 1) / (kRound * a.rounds);
     const long tasks = (long)a.runs_per_field * a.ch_groups * a.fields;
     const unsigned grid = (unsigned)((tasks + kWaves - 1) / kWaves);
-    hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+    hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED, UP>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+}
+
+template <bool FUSED, int UP>
+void launch_fmt(hipStream_t s, const FirArgs& a, int iq_format) {
+    switch (iq_format) {
+        case kIqCs16: launch_mm<kIqCs16, FUSED, UP>(s, a); break;
+        case kIqCs8: launch_mm<kIqCs8, FUSED, UP>(s, a); break;
+        default: launch_mm<kIqCf32, FUSED, UP>(s, a); break;
+    }
 }
 
 template <bool FUSED>
-void launch_fmt(hipStream_t s, const FirArgs& a, int iq_format) {
-    switch (iq_format) {
-        case kIqCs16: launch_mm<kIqCs16, FUSED>(s, a); break;
-        case kIqCs8: launch_mm<kIqCs8, FUSED>(s, a); break;
-        default: launch_mm<kIqCf32, FUSED>(s, a); break;
-    }
+void launch_up(hipStream_t s, const FirArgs& a, int iq_format, int upsample) {
+    if (upsample == 2) launch_fmt<FUSED, 2>(s, a, iq_format);
+    else launch_fmt<FUSED, 1>(s, a, iq_format);
 }
 
 }  // namespace
 
 void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
-                         const float* osc_planes, int channels, int fields, int iq_format) {
+                         const float* osc_planes, int channels, int fields, int iq_format, int upsample) {
     FirArgs a{};
     a.sym = const_cast<uint8_t*>(d_sym);
     a.sym_stride = sym_stride;
@@ -679,12 +716,12 @@ void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride,
     a.planes = osc_planes;
     a.channels = channels;
     a.fields = fields;
-    launch_fmt<false>(s, a, iq_format);
+    launch_up<false>(s, a, iq_format, upsample);
 }
 
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                           size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
-                          int iq_format) {
+                          int iq_format, int upsample) {
     FirArgs a{};
     a.sym = d_sym;   // optional symbol tap
     a.sym_stride = sym_stride;
@@ -699,7 +736,7 @@ void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b
     a.last_group = b.last_group;
     a.fsync = t.fsync;
     a.parity0 = (unsigned)(field_base & 1);
-    launch_fmt<true>(s, a, iq_format);
+    launch_up<true>(s, a, iq_format, upsample);
 }
 
 }  // namespace atsc_k

@@ -77,14 +77,15 @@ void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, 
 hipError_t upload_fft_tables(const float* taps112);
 // Mixer + FIR on the matrix cores for handles with many channels (fir_fused.hip, the form without the symbol producer): osc_planes is the osc_tab memory
 // filled by launch_osc_table(..., planes = true).
+// upsample = 2: the interpolating form, 2 x 260416 samples per field (iq_stride counts output samples)
 void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
-                         const float* osc_planes, int channels, int fields, int iq_format);
-hipError_t upload_mm_tables(const float* taps112);   // fir_fused.hip: the Toeplitz tap operand
+                         const float* osc_planes, int channels, int fields, int iq_format, int upsample);
+hipError_t upload_mm_tables(const float* taps112, const float* taps_half112);   // fir_fused.hip: the Toeplitz tap operands
 // The same with the trellis / map / sync stage fused in: symbols are regenerated from b.il + b.cin inside the kernel and
 // never pass through HBM; d_sym (the symbol tap) may be NULL.  Replaces launch_trellis_map + launch_mix_fir_mfma.
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                           size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
-                          int iq_format);
+                          int iq_format, int upsample);
 constexpr int kFusedGroup = 16;   // channels per wave task of the fused kernel: a partly filled group costs as much as a full one
 
 }  // namespace atsc_k

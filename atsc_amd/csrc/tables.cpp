@@ -155,6 +155,11 @@ void build_taps(Tables& t) {
     }
     for (int n = 0; n < kLen; ++n) t.taps[n] = static_cast<float>(proto[n] * kDcGain / dc);
     t.taps[kLen] = 0.0f;   // 112th tap: pads the filter to a multiple of 16 (filter.h:71 ends in a zero as well)
+    // The interpolating form's second phase (no reference counterpart: the reference runs the radio at the symbol rate,
+    // util/atsc_encoder.cpp:70): the same pulse, same scale, sampled half a symbol later -- y2[2i+1] = sum_k taps_half[k] z[i+k]
+    // sits between y[i] and y[i+1]; 112 taps, symmetric about k = 55.5.
+    for (int n = 0; n < kLen + 1; ++n)
+        t.taps_half[n] = static_cast<float>(rrc_pulse((n - kCentre - 0.5) / kSamplesPerPeriod, kRollOff) * kDcGain / dc);
 }
 
 // ---- oscillator (reference: src/atsc/offset.h:84-106).  NOT an ideal NCO: the phase is computed

@@ -34,6 +34,7 @@ struct Tables {
     uint8_t rs_gen[21];             // g[0..20] ascending
     std::vector<uint8_t> fsync[2];  // 832 B each: field sync segment, even / odd, reserved 12 = 0
     float taps[kTaps];
+    float taps_half[kTaps];   // the same pulse half a symbol later: 112 taps centred between taps 55 and 56 (2x output)
     std::vector<float> osc0;        // 261248 * 2
     float scale[2];
 };

@@ -127,6 +127,9 @@ def parse_args(argv=None):
                     help="SURVEY 8f-1: follow the encoder with the SDR-rate polyphase resampler (include/atsc_hip_resample.h) "
                          "inside the timed step; the line gains a `resampler` object with that kernel's own roofline.  Not "
                          "the headline configuration (the reference runs the radio at the symbol rate)")
+    ap.add_argument("--upsample", type=int, choices=(1, 2), default=1,
+                    help="SURVEY 8f-1: 2 = the interpolating form of the filter (atsc_hip_set_upsample): two samples per symbol "
+                         "out of the same pass, the even ones the reference's.  Not the headline configuration")
     ap.add_argument("--cpu-stub", action="store_true",
                     help="CPU tests: launcher + gloo rendezvous + barrier/max-over-ranks plumbing with the GPU step stubbed")
     args = ap.parse_args(argv)
@@ -302,7 +305,7 @@ def run_gpu(args, json_fd):
     rk.finish()
 
 
-def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world):
+def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world, up=1):
     """Per-stage kernel time from the HIP events of the timed region (this rank's GPU) and the roofline objects."""
     stage_ms = {k: 0.0 for k in atsc_amd.STAGE_NAMES}
     for b in range(args.steps):
@@ -311,7 +314,7 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world)
             stage_ms[k] += tm[k] / args.steps
     sym_per_step_gpu = C_ * F * FIELD_SYMBOLS
     # fused: 64584 interleaved bytes per field in (0.248 B/symbol) + IQ out; separate kernels: 1 B symbol in + IQ out
-    fir_bytes_per_sym = (64584.0 / FIELD_SYMBOLS if fused else 1.0) + sample_bytes
+    fir_bytes_per_sym = (64584.0 / FIELD_SYMBOLS if fused else 1.0) + sample_bytes * up
     if fused and args.symbol_tap:
         fir_bytes_per_sym += 1.0   # the fused kernel also writes the u8 symbols
     fir_s = stage_ms["mix_fir"] / 1e3
@@ -336,7 +339,7 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world)
 
     traffic, traffic_src = None, None
     tj = load_profile_json("traffic.json")
-    if tj and tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8 and \
+    if tj and tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8 and up == 1 and \
             ("fused" in tj.get("kernel", "")) == fused:
         traffic = tj["traffic_bytes_per_launch"]
         traffic_src = {"file": "profiles/r02/traffic.json", "commit": tj.get("commit"),
@@ -357,12 +360,12 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world)
         "avg_launch_ms": round(stage_ms["mix_fir"], 4),
         "note": f"algorithmic bytes = {fir_bytes_per_sym:.3f} B/symbol ("
                 + ("0.248 B interleaved bytes in" if fused else "1 B symbol in")
-                + f" + {sample_bytes} B {args.iq_format} out, SURVEY 8d); peak = the 8 TB/s spec figure (a pure store "
+                + f" + {up} x {sample_bytes} B {args.iq_format} out, SURVEY 8d); peak = the 8 TB/s spec figure (a pure store "
                 "stream of this shape reaches 5.7 TB/s on this part, DESIGN.md)",
-        "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes) * msym_s * 1e6 / world / 1e9, 1),
+        "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes * up) * msym_s * 1e6 / world / 1e9, 1),
     }
     err = load_profile_json("fused_iq_error.json")
-    if fused and err:
+    if fused and err and up == 1:
         roofline["iq_max_abs_error_vs_oracle"] = err
     return stage_ms, roofline, stages
 
@@ -372,6 +375,11 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     enc = atsc_amd.Encoder(channels=C_, max_fields=F, device=rk.local_rank, timing=True)
     enc.set_iq_format(fmt)
     enc.set_fir_form(form)
+    up = args.upsample
+    if up != 1:
+        if args.resample:
+            raise SystemExit("--upsample and --resample are alternatives")
+        enc.set_upsample(up)
     fused = enc.fir_form() == atsc_amd.FIR_FUSED
     ts = make_ts(torch, C_, F, 1234 + rk.rank)     # seeded per rank: every global channel its own stream
     sym = torch.empty(C_ * F * FIELD_SYMBOLS, dtype=torch.uint8, device="cuda") if args.symbol_tap else None
@@ -390,7 +398,7 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         iq_bytes = 8
     else:
         iq_bytes = sample_bytes
-    iq = torch.empty(C_ * F * FIELD_SYMBOLS * iq_bytes, dtype=torch.uint8, device="cuda")
+    iq = torch.empty(C_ * F * FIELD_SYMBOLS * iq_bytes * up, dtype=torch.uint8, device="cuda")
     step_no = [-args.warmup]
 
     def step():
@@ -420,7 +428,7 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
 
     sym_per_step_gpu = C_ * F * FIELD_SYMBOLS
     msym_s = sym_per_step_gpu * args.steps * rk.world / elapsed / 1e6
-    stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, iq_bytes, msym_s, rk.world)
+    stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, iq_bytes, msym_s, rk.world, up)
     resampler = None
     if rs is not None:
         ms = sum(a.elapsed_time(b) for a, b in rs_ev) / args.steps
@@ -452,6 +460,11 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         "roofline": roofline,
         "roofline_other_stages": stages,
     }
+    if up != 1:
+        res["upsample"] = {"factor": up, "out_msamples_s": round(msym_s * up, 1),
+                           "parity": "even samples: the reference's IQ bit for bit (pinned by the oracle); odd samples unpinned (no "
+                                     "reference counterpart), within 1e-5 of a float64 model of the formula (tests/test_gpu_upsample.py)"}
+        res["config"]["workload"] += f"; interpolating filter, {up} samples per symbol out of the same pass"
     if resampler:
         res["resampler"] = resampler
         res["config"]["workload"] += f" + {args.resample} SDR-rate resampler ({args.iq_format} out) inside the step"

@@ -153,6 +153,20 @@ int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);
  * all run the same one for the spans to join bit-identically: atsc_amd/timesplit.py compares this value across ranks. */
 int atsc_hip_get_fir_form(atsc_hip_encoder* enc);
 
+/* Interpolating form of the filter (the "upsampling FIR to the SDR rate"): factor 2 makes every d_iq / h_iq /
+ * callback buffer hold 2 x 260416 samples per field,
+ *     y2[2 i]     = sum_k taps[k]      * z[i + k]      the reference's sample (src/atsc/filter.h:16-69), bit for bit the 1x output
+ *     y2[2 i + 1] = sum_k taps_half[k] * z[i + k]      the same root-raised-cosine pulse, same scale, half a symbol later
+ * (taps_half: 112 taps symmetric about k = 55.5, atsc_hip_get_table), computed in the SAME pass over the symbols by the
+ * matrix-core kernel: a polyphase interpolator by 2 whose phase 0 is the reference filter -- no 1x IQ in HBM, no second
+ * pass.  No reference counterpart (util/atsc_encoder.cpp:70 runs the radio at the symbol rate): the odd samples are
+ * PARITY UNPINNED, checked against a float64 model of the formula and by the spectrum (tests/test_gpu_upsample.py); the
+ * even samples are the reference's.  A 2x handle runs MFMA / FUSED only (AUTO -> FUSED whatever the channel count;
+ * atsc_hip_set_fir_form(FFT) returns ATSC_HIP_ERR_ARG) and needs 16 * max_fields * 260416 * 2 * sample bytes < 4 GiB
+ * (max_fields <= 64 for CF32; ATSC_HIP_ERR_TOO_LARGE otherwise).  Other ratios: atsc_hip_resample.h (a second pass). */
+int atsc_hip_set_upsample(atsc_hip_encoder* enc, int factor); /* 1 (default) or 2 */
+int atsc_hip_get_upsample(atsc_hip_encoder* enc);
+
 /* atsc_hip_process with the radio-side chunking of the reference's transmitter loop (util/atsc_encoder.cpp:84-100:
  * `transfer = min(remaining, MTU)` per writeStream call, chunks never span a field): cb(user, samples, n, format)
  * for every piece of at most mtu_samples samples of every completed field, synchronously and in order. */
@@ -222,7 +236,7 @@ int atsc_hip_batch_timings(atsc_hip_encoder* enc, int batch, float* ms /* [ATSC_
 /* Constant tables as the library built them (host copies), for table parity tests:
  * which: 0 = 112 FIR taps (float), 1 = oscillator T0 (261248 complex64), 2 = scale (2 floats),
  *        3 = PRBS bytes (58344), 4 = field sync even (820 B), 5 = field sync odd (820 B),
- *        6 = RS generator g[0..20].  enc may be NULL (tables do not depend on the device; no GPU needed). */
+ *        6 = RS generator g[0..20], 7 = the 112 half-symbol taps of the 2x form (float).  enc may be NULL (tables do not depend on the device; no GPU needed). */
 int atsc_hip_get_table(atsc_hip_encoder* enc, int which, void* h_out, size_t bytes);
 
 const char* atsc_hip_error_string(int code);
