@@ -29,6 +29,10 @@ public:
     // loop's chunking: write(samples, n) for every piece of at most mtu samples of every completed field.
     enum class iq_format { cf32 = ATSC_HIP_IQ_CF32, cs16 = ATSC_HIP_IQ_CS16, cs8 = ATSC_HIP_IQ_CS8 };
     virtual void set_iq_format(iq_format f) = 0;
+    // 2: the interpolating form of the filter (atsc_hip_set_upsample): two samples per symbol, for a radio run at twice the
+    // symbol rate (setSampleRate(2 * 4500000.0 / 286 * 684) instead of util/atsc_encoder.cpp:70); fn / write then see
+    // 2 x 260416 samples per field, the even ones the reference's
+    virtual void set_upsample(int factor) = 0;
     virtual void process_chunked(uint8_t* pkt, unsigned count, size_t mtu_samples,
                                  std::function<void(const void*, size_t)> write) = 0;
 
@@ -61,6 +65,10 @@ public:
     void set_iq_format(iq_format f) override {
         const int rc = atsc_hip_set_iq_format(h_, static_cast<int>(f));
         if (rc != ATSC_HIP_OK) throw std::runtime_error(std::string("atsc_hip_set_iq_format: ") + atsc_hip_error_string(rc));
+    }
+    void set_upsample(int factor) override {
+        const int rc = atsc_hip_set_upsample(h_, factor);
+        if (rc != ATSC_HIP_OK) throw std::runtime_error(std::string("atsc_hip_set_upsample: ") + atsc_hip_error_string(rc));
     }
     void process_chunked(uint8_t* pkt, unsigned count, size_t mtu_samples,
                          std::function<void(const void*, size_t)> write) override {

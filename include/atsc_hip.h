@@ -82,7 +82,7 @@ void atsc_hip_destroy(atsc_hip_encoder* enc);
 /* Replaces atsc::atsc_encoder::process (src/atsc/atsc.cpp:59-77) for a 1-channel handle:
  * `count` contiguous 188-byte TS packets (host memory, copied before return); every completed
  * 312-packet field fires cb(user, iq, bytes) synchronously, in order, before the call returns; bytes = 260416 x the
- * handle's sample size: 2083328 for CF32 (the reference's payload), 1041664 for CS16, 520832 for CS8.
+ * handle's sample size: 2083328 for CF32 (the reference's payload), 1041664 for CS16, 520832 for CS8; twice that on a handle with atsc_hip_set_upsample(2).
  * All complete fields available are encoded in GPU batches of up to max_fields; when a call completes several
  * batches, the upload and kernels of batch k+1 overlap the download and callbacks of batch k (two internal slots
  * and streams) -- nothing stays in flight when the call returns.  A trailing partial field stays buffered (no flush
