@@ -63,14 +63,14 @@ def check_uniform(values, group=None, device="cpu"):
     for q, other in enumerate(_gather(mine, group)):
         if other.cpu().tolist() != list(values):
             raise atsc_amd.AtscHipError(
-                f"time-split ranks disagree: rank {dist.get_rank(group)} has (channels, fir_form, iq_format) = "
+                f"time-split ranks disagree: rank {dist.get_rank(group)} has (channels, fir_form, iq_format, ...) = "
                 f"{list(values)}, rank {q} has {other.cpu().tolist()}; the spans would not join bit-identically")
 
 
 class TimeSplitEncoder:
     """One rank's share of a time-split: fields [first_field, first_field + fields) of `channels` streams."""
 
-    def __init__(self, fields, device=0, channels=1, fir_form=atsc_amd.FIR_AUTO, iq_format=atsc_amd.IQ_CF32):
+    def __init__(self, fields, device=0, channels=1, fir_form=atsc_amd.FIR_AUTO, iq_format=atsc_amd.IQ_CF32, upsample=1):
         self.fields = fields
         self.device = device
         self.channels = channels
@@ -78,6 +78,7 @@ class TimeSplitEncoder:
         self.enc = atsc_amd.Encoder(channels=channels, max_fields=fields, device=device)
         self.enc.set_fir_form(fir_form)
         self.enc.set_iq_format(iq_format)
+        self.enc.set_upsample(upsample)      # 2: d_iq holds 2 x 260416 samples per field (a field is self-contained in both forms)
         self._checked = False
 
     def prepare(self, first_field, halo_field_ts=None):
@@ -100,7 +101,7 @@ class TimeSplitEncoder:
         """begin -> exchange span parities -> finish.  d_ts/d_sym/d_iq: device tensors of this span
         ([channels][fields][...])."""
         if not self._checked:
-            check_uniform((self.channels, self.enc.fir_form(), self.iq_format), group,
+            check_uniform((self.channels, self.enc.fir_form(), self.iq_format, self.enc.upsample()), group,
                           device=d_ts.device if _is_nccl(group) else "cpu")
             self._checked = True
         stream = torch.cuda.current_stream().cuda_stream

@@ -161,3 +161,33 @@ def test_limits_and_streaming():
     enc.process(ts, nf * 312, on_field)
     assert len(got) == nf and all(g.size == 2 * FIELD_SYMBOLS * 8 for g in got)
     assert np.array_equal(np.concatenate(got), want)
+
+
+def test_time_split_spans_join_bit_identically_at_two_samples_per_symbol():
+    """BASELINE config 5 on a 2x handle: 3 spans x 2 fields of 16 streams, each span a cold handle primed from a one-field
+    halo with the trellis carry handed over, give the bits of one handle encoding the 6 fields in one go (a field is
+    self-contained in the interpolating form as well: nothing of the filter crosses a field boundary)."""
+    import torch
+    from atsc_amd.timesplit import TimeSplitEncoder
+    C_, R, nf = 16, 3, 2
+    g = torch.Generator(device="cuda")
+    g.manual_seed(321)
+    ts = torch.randint(0, 256, (C_, R * nf, 312 * 188), dtype=torch.uint8, device="cuda", generator=g)
+    ts.view(C_, R * nf, 312, 188)[..., 0] = 0x47
+    st = torch.cuda.current_stream().cuda_stream
+    cont = atsc_amd.Encoder(channels=C_, max_fields=R * nf)
+    cont.set_upsample(2)
+    iq_c = torch.empty(C_, R * nf, 2 * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+    cont.encode_batch(ts.data_ptr(), R * nf, None, iq_c.data_ptr(), st)
+    carry = torch.zeros(4 * C_, dtype=torch.int32, device="cuda")
+    for r in range(R):
+        t = TimeSplitEncoder(nf, channels=C_, upsample=2)
+        t.prepare(r * nf, ts[:, r * nf - 1].contiguous() if r else None)
+        span = ts[:, r * nf:(r + 1) * nf].contiguous()
+        d_iq = torch.empty(C_, nf, 2 * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+        this_carry = carry.clone()
+        par = t.encode(span, None, d_iq, exchange=lambda p, grp: this_carry)
+        torch.cuda.synchronize()
+        same = torch.view_as_real(d_iq).view(torch.int32) == torch.view_as_real(iq_c[:, r * nf:(r + 1) * nf].contiguous()).view(torch.int32)
+        assert bool(same.all()), f"span {r}: IQ bits differ"
+        carry = carry ^ par
