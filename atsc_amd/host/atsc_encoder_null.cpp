@@ -4,7 +4,7 @@
 // option, a throughput report, the SDR sample formats, and the TS ingest front-end (include/atsc_ts_ingest.h): the
 // input may be an unaligned / damaged byte stream; with "pad" the last partial field is completed with null packets
 // instead of being dropped (the reference drops it, util/atsc_encoder_null.cpp:40).
-//   usage: atsc_encoder_null <file|-> [fields_per_call=8] [device=0] [cf32|cs16|cs8] [pad]
+//   usage: atsc_encoder_null <file|-> [fields_per_batch=8] [device=0] [cf32|cs16|cs8] [pad]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +16,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: %s <ts-file|-> [fields_per_call] [device] [cf32|cs16|cs8] [pad]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <ts-file|-> [fields_per_batch] [device] [cf32|cs16|cs8] [pad]\n", argv[0]);
         return 2;
     }
     const int batch = argc > 2 ? std::max(1, std::atoi(argv[2])) : 8;
@@ -39,7 +39,9 @@ int main(int argc, char** argv) {
     }
     const bool pad = argc > 5 && !std::strcmp(argv[5], "pad");
     atsc_ts_ingest* ing = atsc_ts_ingest_create(0, 0);
-    const size_t call_packets = static_cast<size_t>(batch) * ATSC_HIP_PACKETS_PER_FIELD;
+    // four GPU batches per process() call: inside a call the upload and kernels of batch k+1 overlap the download and the
+    // callbacks of batch k (include/atsc_hip.h); a call with a single batch cannot overlap anything
+    const size_t call_packets = static_cast<size_t>(4 * batch) * ATSC_HIP_PACKETS_PER_FIELD;
     std::vector<uint8_t> chunk(1 << 20), buf(call_packets * ATSC_HIP_TS_PACKET_BYTES);
     unsigned long long fields = 0, bytes_out = 0;
     auto sink = [&](void*, unsigned n) {
