@@ -29,8 +29,9 @@ namespace atsc_k {
 // The dropped TS sync byte (randomize.h:48) is fed as a zero, which leaves a zero state untouched, so a packet is
 // exactly 47 steps.  The code is GF(2)-linear, so the raw TS bytes are encoded and the (precomputed) parity of the
 // packet's PRBS row is added at the end.  The row lookups are the cost: lanes read random rows, so the tables sit in
-// LDS in a bank-spread image (4 copies of the 16-byte part, 8 of the 4-byte part; lanes that share a copy collide only
-// within v mod 4), and nothing else lives in LDS so that 16 waves per CU hide the lookup latency.
+// LDS in a bank-spread image (8 copies of the 16-byte part, 8 of the 4-byte part: together the CU's whole 160 KB; the two
+// lanes of a 16-lane service group that share a copy collide only when their rows have the same parity), and nothing else
+// lives in LDS so that 16 waves per CU hide the lookup latency.
 //
 // k_assemble (debug tap, ATSC_HIP_FLAG_TAPS): coded[207 s + k] = ts[188 s + 1 + k] ^ prbs[187 s + k] (k < 187) followed
 // by the 20 parity bytes: a byte-shifting copy, staged through LDS rows of 212 bytes with coalesced loads and stores.
@@ -42,16 +43,20 @@ typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 __global__ __launch_bounds__(kRsThreads) void k_rs_parity(const uint8_t* __restrict__ ts, const uint4* __restrict__ rs_lds,
                                                           const uint4* __restrict__ prbs_parity,
                                                           uint4* __restrict__ parity, long npackets) {
-    __shared__ uint4 s_a[4 * 256 * 4];      // 65536 B
+    constexpr int kCopies = 8;              // of the 16-byte parts: 8 x 16 KB + 32 KB below = all of the CU's 160 KB (4 copies: +8 %)
+    __shared__ uint4 s_a[4 * 256 * kCopies];
     __shared__ uint32_t s_e[4 * 256 * 8];   // 32768 B
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_a[tid + kRsThreads * i] = rs_lds[tid + kRsThreads * i];
+    for (int i = 0; i < 4 * kCopies / 4; ++i) {
+        const int idx = tid + kRsThreads * i;
+        s_a[idx] = rs_lds[(idx / kCopies) * 4 + (idx & 3)];     // (the host image holds four copies per row)
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) reinterpret_cast<uint4*>(s_e)[tid + kRsThreads * i] = rs_lds[4096 + tid + kRsThreads * i];
     __syncthreads();
 
-    const uint4* ta = s_a + (tid & 3);
+    const uint4* ta = s_a + (tid & (kCopies - 1));
     const uint32_t* te = s_e + (tid & 7);
     for (long P = (long)blockIdx.x * kRsThreads + tid; P < npackets; P += (long)gridDim.x * kRsThreads) {
         uint32_t d[48];
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_parity(const uint8_t* __restr
             // first byte in time = lowest byte = four steps from the end -> table T4 (index 3)
             const uint32_t i4 = 3 * 256 + (u & 0xffu), i3 = 2 * 256 + ((u >> 8) & 0xffu), i2 = 256 + ((u >> 16) & 0xffu),
                            i1 = u >> 24;
-            const uint4 r4 = ta[i4 * 4], r3 = ta[i3 * 4], r2 = ta[i2 * 4], r1 = ta[i1 * 4];
+            const uint4 r4 = ta[i4 * kCopies], r3 = ta[i3 * kCopies], r2 = ta[i2 * kCopies], r1 = ta[i1 * kCopies];
             const uint32_t e = te[i4 * 8] ^ te[i3 * 8] ^ te[i2 * 8] ^ te[i1 * 8];
             b0 = b1 ^ r4.x ^ r3.x ^ r2.x ^ r1.x;
             b1 = b2 ^ r4.y ^ r3.y ^ r2.y ^ r1.y;
