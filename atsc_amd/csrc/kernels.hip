@@ -236,15 +236,14 @@ constexpr int kIlSegs = kCkBytes / kSegCoded;      // 52 segments of 207 interle
 constexpr int kIlThreads = 512;
 constexpr int kIlIts = (kIlTasks + kIlThreads - 1) / kIlThreads;
 static_assert(kIlIts == 2, "two tasks per thread");
-constexpr int kTsSlots = kCkPk * 11;                                         // 572 sixteen-byte pieces of TS data per chunk
-constexpr int kIlTsWaves1 = (kTsSlots - kIlThreads + 63) / 64;              // waves whose second staging task is a TS piece
+constexpr int kIlPkPerWave = 5;                                              // TS staging: five packets x 11 pieces = 55 lanes of a wave
+constexpr int kIlTsWaves1 = (kCkPk - 8 * kIlPkPerWave + kIlPkPerWave - 1) / kIlPkPerWave;   // waves with a second TS task: 3
 constexpr int kIlBWave = kIlTsWaves1, kIlCWave = kIlTsWaves1 + 1;           // waves whose second task is a packet's tail / parity
 constexpr int kIlGatherWaves1 = (kIlTasks - kIlThreads + 63) / 64;          // waves with a second gather task
 constexpr int kIlStoreWaves1 = (kIlPieces - kIlThreads + 63) / 64;          // waves with a second piece to store
-constexpr int kIlParTid0 = 64 * (kIlCWave + 1);                              // the parity threads start behind those waves
-constexpr int kIlFoldTid0 = kIlThreads - 64;                                 // the last wave folds
-static_assert(kIlParTid0 + kIlSegs * 3 <= kIlFoldTid0 + 64, "parity threads");
-constexpr int kPartBytes = kPartGroups * 12;       // 2484 interleaved bytes per part
+constexpr int kIlParTid0 = 64 * (kIlCWave + 1);                              // the parity threads: the three waves behind those
+constexpr int kIlFoldTid0 = 64 * kIlCWave;                                   // the wave with the lightest second task folds
+static_assert(kIlThreads == 512 && kIlParTid0 + kIlSegs * 3 <= kIlThreads, "wave roles");
 
 typedef uint32_t u32x4a1 __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint32_t u32x2a1 __attribute__((ext_vector_type(2), aligned(1)));
@@ -266,16 +265,17 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
                                                            const uint8_t* __restrict__ prbs_rows, uint8_t* __restrict__ il,
                                                            size_t il_stride, uint32_t* __restrict__ par, int fields,
                                                            int fields_per_block) {
-    __shared__ uint32_t s_pkt[(kIlRing + kIlMirror) * kIlRowDw];   // 23320 B
+    __shared__ uint32_t s_pkt_mem[1 + (kIlRing + kIlMirror) * kIlRowDw];   // 23324 B: a guard dword, then the rows
+    uint32_t* const s_pkt = s_pkt_mem + 1;
     __shared__ __align__(16) uint32_t s_out[kCkDw + 5];            // the chunk in transmission order
-    __shared__ uint32_t s_par[8 * 3];                              // XOR of the data dwords per (part mod 8, word)
+    __shared__ uint32_t s_par[16 * 3];                             // XOR of the data dwords per (part mod 16, word)
     const int tid = threadIdx.x;
     const int c = blockIdx.y;
     const int f0 = blockIdx.x * fields_per_block, f1 = min(fields, f0 + fields_per_block);
     const uint8_t* ts_c = ts + (size_t)c * ts_stride;
     const uint8_t* rec_c = parity + (size_t)c * fields * (kPackets * 32);
     uint8_t* il_c = il + (size_t)c * il_stride;
-    if (tid < 8 * 3) s_par[tid] = 0;
+    if (tid < 16 * 3) s_par[tid] = 0;
 
     // This kernel is bound by instruction issue, not by a memory: everything that does not change from chunk to chunk
     // (task geometry, LDS addresses, offsets from the chunk's base pointers) is computed here, once.
@@ -297,45 +297,48 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         g_src[it][1] = s_pkt + first * kIlRowDw + hi;
         g_dst[it] = s_out + a0 * 13 + lo;
     }
-    // ---- staging tasks: 16 bytes of a packet's LDS row each.  A vector memory instruction costs its pipe the same with 4
-    // lanes active as with 64, so the kinds of task are sorted into whole waves:
-    //   slots 0..571 (first task of every thread, second task of the first wave(s)): packet q = slot / 11, piece p = slot % 11:
-    //       TS bytes 1 + 16 p .. of the packet, one unaligned load (coded byte t of a packet is TS byte t + 1, randomize.h:48)
-    //   second task of wave kIlBWave: packet q = lane: TS bytes 177..187, the first parity byte and parity bytes 1..4
-    //   second task of wave kIlCWave: packet q = lane: parity bytes 5..19
+    // ---- staging tasks: 16 bytes of TS or parity each.  A vector memory instruction costs its pipe the same with 4 lanes
+    // active as with 64, and a load that is not dword-aligned costs it double (measured: 10 % of this kernel), so the loads are
+    // aligned and the one-byte shift between TS and coded bytes (coded byte t of a packet is TS byte t + 1, randomize.h:48) is
+    // done in registers; the kinds of task are sorted into whole waves:
+    //   TS task (packet q, piece p < 11), 55 lanes = five packets per wave, both passes: TS dwords 4p .. 4p+3 -> coded dwords
+    //       4p-1 .. 4p+2 (the byte in front comes from the lane below; for p = 0 the dword in front of the row is the padding
+    //       dword of the row before it, or the guard dword)
+    //   second task of wave kIlBWave, packet q = lane: TS dwords 43..46 -> coded dwords 43..46 with the first parity byte, and
+    //       parity bytes 1..4 (parity record dwords 0, 1)
+    //   second task of wave kIlCWave, packet q = lane: parity bytes 5..19 (record dwords 2..5)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // The lanes of a wave issue the same loads (no lane-dependent branches between them: a merge of registers after such a
     // branch makes the compiler wait for the data there, which would serialise the prefetch); lanes without a task load
     // offset 0 and drop it.
-    bool st_ok, st_mirror[2];
+    bool st_ok[2], st_mirror[2];
     uint32_t a_off[2], pr_off[2], rec_off = 0;
     uint32_t* st_dst[2][2];
     {
         int q[2], p[2];
-        q[0] = tid / 11;
-        p[0] = tid - 11 * q[0];
-        a_off[0] = q[0] * kTsBytes + 1 + 16 * p[0];
-        pr_off[0] = q[0] * 208 + 16 * p[0];
-        if (wave < kIlTsWaves1) {
-            const int id = tid + kIlThreads;
-            st_ok = id < kTsSlots;
-            q[1] = st_ok ? id / 11 : 0;
-            p[1] = st_ok ? id - 11 * q[1] : 0;
-            a_off[1] = q[1] * kTsBytes + 1 + 16 * p[1];
-            pr_off[1] = q[1] * 208 + 16 * p[1];
-        } else {
-            st_ok = wave <= kIlCWave && lane < kCkPk;
-            q[1] = st_ok ? lane : 0;
-            p[1] = wave == kIlBWave ? 11 : 12;    // row dwords 44.. / 48..
-            // B: TS bytes 172..187 (aligned; used from byte 177 on) + parity record dwords 0, 1; C: record dwords 2..5
+        const int lq = lane / 11, lp = lane - 11 * lq;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            q[it] = kIlPkPerWave * (wave + 8 * it) + lq;
+            p[it] = lp;
+            st_ok[it] = lq < kIlPkPerWave && q[it] < kCkPk && (it == 0 || wave < kIlTsWaves1);
+            if (!st_ok[it]) q[it] = p[it] = 0;
+            a_off[it] = q[it] * kTsBytes + 16 * p[it];
+            pr_off[it] = q[it] * 208 + 16 * p[it];          // relative to four bytes in front of the chunk's PRBS rows (fetch)
+            st_dst[it][0] = s_pkt + q[it] * kIlRowDw + 4 * p[it] - 1;
+        }
+        if (wave == kIlBWave || wave == kIlCWave) {
+            st_ok[1] = lane < kCkPk;
+            q[1] = st_ok[1] ? lane : 0;
+            // B: TS bytes 172..187 + parity record dwords 0, 1; C: record dwords 2..5
             a_off[1] = wave == kIlBWave ? q[1] * kTsBytes + 172 : q[1] * 32 + 8;
-            pr_off[1] = q[1] * 208 + (wave == kIlBWave ? 176 : 192);    // row bytes 187..207 of the table are zero
+            pr_off[1] = q[1] * 208 + 4 + (wave == kIlBWave ? 172 : 192);    // row bytes 187..207 of the table are zero
             rec_off = q[1] * 32;
+            st_dst[1][0] = s_pkt + q[1] * kIlRowDw + (wave == kIlBWave ? 43 : 48);
         }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             st_mirror[it] = q[it] < kIlMirror;
-            st_dst[it][0] = s_pkt + q[it] * kIlRowDw + 4 * p[it];
             st_dst[it][1] = st_dst[it][0] + kCkPk * kIlRowDw;
         }
     }
@@ -357,44 +360,78 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
     auto fetch = [&](int kk) {
         const uint64_t tsk = scalar_addr(reinterpret_cast<uint64_t>(ts_c) + (uint64_t)kk * kCkTs);
         const uint64_t reck = scalar_addr(reinterpret_cast<uint64_t>(rec_c) + (uint64_t)kk * (kCkPk * 32));
-        const uint64_t prk = scalar_addr(reinterpret_cast<uint64_t>(prbs_rows) + (uint32_t)(kk % kCkPerField) * (kCkPk * 208));
+        // Coded dwords 4p-1.. of a TS task start four bytes in front of the PRBS piece 16p: the base is moved, not the unsigned
+        // lane offsets.  For the first row of the table those four bytes are the end of the table in front of it in the same
+        // allocation (atsc_hip.cpp: off_prr >= 256); the value lands in a padding dword.
+        const uint64_t prk = scalar_addr(reinterpret_cast<uint64_t>(prbs_rows) + (uint32_t)(kk % kCkPerField) * (kCkPk * 208) - 4);
         const uint64_t base1 = wave == kIlCWave ? reck : tsk;
         va[0] = *reinterpret_cast<const ATSC_GLOBAL u32x4a1*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(tsk) + a_off[0]);
-        vb[0] = *reinterpret_cast<const ATSC_GLOBAL u32x4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[0]);
+        vb[0] = *reinterpret_cast<const ATSC_GLOBAL u32x4a4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[0]);
         if (wave <= kIlCWave) {      // (wave-uniform)
             va[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4a1*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(base1) + a_off[1]);
-            vb[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[1]);
+            vb[1] = *reinterpret_cast<const ATSC_GLOBAL u32x4a4*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(prk) + pr_off[1]);
             vr = *reinterpret_cast<const ATSC_GLOBAL u32x2*>(reinterpret_cast<const ATSC_GLOBAL uint8_t*>(reck) + rec_off);
         }
     };
+    // TS task: loaded dwords d0..d3 = TS dwords 4p..4p+3 -> coded dwords 4p-1..4p+2, each the upper three bytes of one TS dword and
+    // the lowest byte of the next; `below` is d3 of the lane below (the piece in front)
+    auto ts_shift = [&](const u32x4a1& v, uint32_t below, uint32_t (&x)[4]) {
+        x[0] = __builtin_amdgcn_alignbyte(v.x, below, 1);
+        x[1] = __builtin_amdgcn_alignbyte(v.y, v.x, 1);
+        x[2] = __builtin_amdgcn_alignbyte(v.z, v.y, 1);
+        x[3] = __builtin_amdgcn_alignbyte(v.w, v.z, 1);
+    };
     auto commit = [&](auto half_c) {
         constexpr int H = decltype(half_c)::value;
-        uint32_t a1[4] = {va[1].x, va[1].y, va[1].z, va[1].w}, e1 = 0;
-        if (wave == kIlBWave) {
-            // loaded TS bytes 172..187; coded bytes 176..186 are TS bytes 177..187; then the first parity byte (already in
-            // the top byte, k_rs_parity) and parity bytes 1..4
-            a1[0] = __builtin_amdgcn_alignbyte(a1[2], a1[1], 1);
-            a1[1] = __builtin_amdgcn_alignbyte(a1[3], a1[2], 1);
-            a1[2] = a1[3] >> 8;
-            a1[3] = vr.y;
-            e1 = vr.x;
-        }
+        const uint32_t below0 = __shfl_up(va[0].w, 1, 64), below1 = __shfl_up(va[1].w, 1, 64);   // (every lane takes part)
         {
-            uint32_t* dst = st_dst[0][H];
-            const uint32_t x0 = va[0].x ^ vb[0].x, x1 = va[0].y ^ vb[0].y, x2 = va[0].z ^ vb[0].z, x3 = va[0].w ^ vb[0].w;
-            dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
-            if (H == 0 && st_mirror[0]) {
-                dst += kIlRing * kIlRowDw;
+            uint32_t x[4];
+            ts_shift(va[0], below0, x);
+            if (st_ok[0]) {
+                uint32_t* dst = st_dst[0][H];
+                const uint32_t x0 = x[0] ^ vb[0].x, x1 = x[1] ^ vb[0].y, x2 = x[2] ^ vb[0].z, x3 = x[3] ^ vb[0].w;
                 dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+                if (H == 0 && st_mirror[0]) {
+                    dst += kIlRing * kIlRowDw;
+                    dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+                }
             }
         }
-        if (st_ok) {
-            uint32_t* dst = st_dst[1][H];
-            const uint32_t x0 = a1[0] ^ vb[1].x, x1 = a1[1] ^ vb[1].y, x2 = (a1[2] ^ vb[1].z) | e1, x3 = a1[3] ^ vb[1].w;
-            dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
-            if (H == 0 && st_mirror[1]) {
-                dst += kIlRing * kIlRowDw;
+        if (wave < kIlTsWaves1) {
+            uint32_t x[4];
+            ts_shift(va[1], below1, x);
+            if (st_ok[1]) {
+                uint32_t* dst = st_dst[1][H];
+                const uint32_t x0 = x[0] ^ vb[1].x, x1 = x[1] ^ vb[1].y, x2 = x[2] ^ vb[1].z, x3 = x[3] ^ vb[1].w;
                 dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+                if (H == 0 && st_mirror[1]) {
+                    dst += kIlRing * kIlRowDw;
+                    dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3;
+                }
+            }
+        } else if (wave == kIlBWave) {
+            // TS dwords 43..46 -> coded dwords 43..46 (TS bytes 173..187 and, in the top byte of the last one, the first parity
+            // byte, which k_rs_parity left there), then parity bytes 1..4
+            if (st_ok[1]) {
+                uint32_t* dst = st_dst[1][H];
+                const uint32_t x0 = __builtin_amdgcn_alignbyte(va[1].y, va[1].x, 1) ^ vb[1].x,
+                               x1 = __builtin_amdgcn_alignbyte(va[1].z, va[1].y, 1) ^ vb[1].y,
+                               x2 = __builtin_amdgcn_alignbyte(va[1].w, va[1].z, 1) ^ vb[1].z,
+                               x3 = ((va[1].w >> 8) ^ vb[1].w) | vr.x, x4 = vr.y;
+                dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3; dst[4] = x4;
+                if (H == 0 && st_mirror[1]) {
+                    dst += kIlRing * kIlRowDw;
+                    dst[0] = x0; dst[1] = x1; dst[2] = x2; dst[3] = x3; dst[4] = x4;
+                }
+            }
+        } else if (wave == kIlCWave) {
+            if (st_ok[1]) {
+                uint32_t* dst = st_dst[1][H];
+                dst[0] = va[1].x; dst[1] = va[1].y; dst[2] = va[1].z; dst[3] = va[1].w;
+                if (H == 0 && st_mirror[1]) {
+                    dst += kIlRing * kIlRowDw;
+                    dst[0] = va[1].x; dst[1] = va[1].y; dst[2] = va[1].z; dst[3] = va[1].w;
+                }
             }
         }
     };
@@ -434,6 +471,25 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
     __syncthreads();
 
     // one chunk: kk in the batch, kf in its field (kf & 1 == H)
+    // The parts that ended inside chunk kf of field f are complete once that chunk's barrier has passed: one wave (the one
+    // whose second staging task is the lightest) turns them into parities.  It does so one chunk LATER, beside the other
+    // waves' store pass (measured with cycle-counter probes: done right behind the barrier it made this wave 1500 cycles
+    // late at the next one, where seven waves waited);
+    // the slots are indexed by part mod 16 so that the parts of the following chunk never land on one still to be folded.
+    auto fold = [&](int kf, int f) {
+        const int done_before = (kf * kIlSegs) / 12, done_after = ((kf + 1) * kIlSegs) / 12;
+        const int ft = tid - kIlFoldTid0;
+        if (ft >= 0 && ft < (done_after - done_before) * 3) {
+            const int pi = ft / 3, k = ft - 3 * pi;
+            const int slot = ((done_before + pi) & 15) * 3 + k;
+            uint32_t* o = par + (((size_t)c * fields + f) * kParts + done_before + pi) * 4;
+            uint32_t z2, z0, pr;
+            trellis_local(s_par[slot], z2, z0, pr);
+            o[k] = pr;
+            if (k == 0) o[3] = 0;
+            s_par[slot] = 0;
+        }
+    };
     auto chunk = [&](int kk, int kf, int f, auto half_c) {
         constexpr int H = decltype(half_c)::value;
         const bool more = kk + 1 < kk_end;
@@ -461,6 +517,7 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
             }
         }
         __syncthreads();
+        if (kk > kk_first) fold(kf ? kf - 1 : kCkPerField - 1, kf ? f : f - 1);
         // ---- the chunk leaves as 16-byte pieces
         const uint64_t dst = scalar_addr(reinterpret_cast<uint64_t>(il_c) + (uint64_t)kk * kCkBytes);
         {
@@ -490,23 +547,10 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
             for (int i = 0; i < 17; ++i) acc ^= sg_src[3 * i];
             const int r = 4 * kf + sg;                       // segment of the field = 48 kf + r, r < 72
             const int S = kf * kIlSegs + sg;
-            atomicXor(&s_par[((4 * kf + r / 12) & 7) * 3 + (sw + S) % 3], acc);
+            atomicXor(&s_par[((4 * kf + r / 12) & 15) * 3 + (sw + S) % 3], acc);
         }
         if (more) commit(IntC<H ^ 1>());
         __syncthreads();
-        // ---- parts that ended inside this chunk are complete
-        const int done_before = (kf * kCkBytes) / kPartBytes, done_after = ((kf + 1) * kCkBytes) / kPartBytes;
-        const int ft = tid - kIlFoldTid0;
-        if (ft >= 0 && ft < (done_after - done_before) * 3) {
-            const int pi = ft / 3, k = ft - 3 * pi;
-            const int slot = ((done_before + pi) & 7) * 3 + k;
-            uint32_t* o = par + (((size_t)c * fields + f) * kParts + done_before + pi) * 4;
-            uint32_t z2, z0, pr;
-            trellis_local(s_par[slot], z2, z0, pr);
-            o[k] = pr;
-            if (k == 0) o[3] = 0;
-            s_par[slot] = 0;
-        }
     };
     int kk = kk_first;
 #pragma unroll 1
@@ -518,6 +562,7 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
             kk += 2;
         }
     }
+    fold(kCkPerField - 1, f1 - 1);      // (behind the last chunk's closing barrier)
 }
 
 // Coded tail of the batch (the last 10608 RS-coded bytes) for the next batch's first block and for state export.
