@@ -343,7 +343,7 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world,
             ("fused" in tj.get("kernel", "")) == fused:
         traffic = tj["traffic_bytes_per_launch"]
         traffic_src = {"file": "profiles/r02/traffic.json", "commit": tj.get("commit"),
-                       "note": "PMC passes of scripts/pmc_traffic.sh on the named commit; not re-measured in this run"}
+                       "note": "PMC passes of scripts/profile_gpu.sh (fetch, write) on the named commit, summarised by scripts/summarize_profile.py; not re-measured in this run"}
     roofline = {
         "kernel": ("k_mix_fir_mm<cf32, fused> (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes, "
                    "pilot + offset mixer first, then the 112-tap RRC FIR as Y = A.Z with a constant Toeplitz tap operand on the "
