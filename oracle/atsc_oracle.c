@@ -100,34 +100,25 @@ static void init_fsync(void) {
     }
 }
 
-/* RRC taps: the reference hard-codes 112 floats (src/atsc/filter.h:71); SURVEY.md 8(a8) shows they
- * are root_raised_cosine(gain 0.1, fs = Rs, symbol rate Rs/2, alpha 0.1152, 111 taps) evaluated in
- * double and rounded to float, plus one zero pad (generator: src/common/filter.h:15-55). */
+/* RRC taps.  The reference holds them as 111 literal constants and a closing zero (src/atsc/filter.h:71); they are the
+ * root-raised-cosine pulse h(u) = [sin(pi u (1-a)) + 4 a u cos(pi u (1+a))] / [pi u (1 - (4 a u)^2)], h(0) = 1 - a + 4a/pi,
+ * at u = (n - 55)/2, roll-off a = 0.1152, rounded to float and then scaled to a DC gain of 0.1.  Evaluated
+ * from that textbook form; tests/test_oracle.py pins all 112 bit patterns to tests/golden/golden.json["taps_bits"], which
+ * were read out of the compiled reference. */
+static double rrc_at(double u, double a) {
+    if (u == 0.0) return 1.0 - a + 4.0 * a / M_PI;
+    double w = 4.0 * a * u; /* never +-1 here: 0.2304 k is not 1 for an integer k */
+    return (sin(M_PI * u * (1.0 - a)) + w * cos(M_PI * u * (1.0 + a))) / (M_PI * u * (1.0 - w * w));
+}
+
 static void init_taps(void) {
-    const double alpha = 0.1152, gain = 0.1, spb = 2.0;
-    const int ntaps = 111;
-    double sum = 0;
-    float t[111];
-    for (int i = 0; i < ntaps; i++) {
-        double xi = i - ntaps / 2;
-        double x1 = M_PI * xi / spb, x2 = 4 * alpha * xi / spb, x3 = x2 * x2 - 1, num, den;
-        if (fabs(x3) >= 0.000001) {
-            if (i != ntaps / 2)
-                num = cos((1 + alpha) * x1) + sin((1 - alpha) * x1) / (4 * alpha * xi / spb);
-            else
-                num = cos((1 + alpha) * x1) + (1 - alpha) * M_PI / (4 * alpha);
-            den = x3 * M_PI;
-        } else {
-            x3 = (1 - alpha) * x1;
-            x2 = (1 + alpha) * x1;
-            num = sin(x2) * (1 + alpha) * M_PI - cos(x3) * ((1 - alpha) * M_PI * spb) / (4 * alpha * xi) +
-                  sin(x3) * spb * spb / (4 * alpha * xi * xi);
-            den = -32 * M_PI * alpha * alpha * xi / spb;
-        }
-        t[i] = (float)(4 * alpha * num / den);
-        sum += t[i];
+    float shape[111];
+    double total = 0;
+    for (int n = 0; n < 111; n++) {
+        shape[n] = (float)rrc_at((n - 55) / 2.0, 0.1152);
+        total += shape[n];
     }
-    for (int i = 0; i < ntaps; i++) g_taps[i] = (float)(t[i] * gain / sum);
+    for (int n = 0; n < 111; n++) g_taps[n] = (float)(shape[n] * 0.1 / total);
     g_taps[111] = 0.0f;
 }
 
