@@ -178,6 +178,27 @@ struct FirArgs {
 // i.e. a polyphase interpolator by 2 whose phase 0 is the reference filter; one pass over the symbols, no 1x IQ in HBM.  54
 // MFMAs per tile on two accumulators, the Z operand is converted once; both A operands stay in registers, so one wave per
 // SIMD (and the kernel becomes matrix-pipe- and store-bound: twice the products, twice the bytes).
+// Which of the three fp16 products a K-step needs.  Y = Ahi.Zhi + Alo.Zhi + Ahi.Zlo; the two low-order products correct the
+// rounding of the taps (|Alo| <= 2^-11 |tap|, and the remainders are constants) and of z (|Zlo| <= 2 * 2^-11 |z|: the
+// oscillator's split and the product's rounding).  A K-step holds taps k - p for its 16 inputs k and the tile's 32 outputs p,
+// and the taps of the outer K-steps are small: the largest sum over a row of K-steps 0, 1, 7, 8 is 0.0006, 0.0016, 0.0014,
+// 0.0005 of sum |tap| = 0.189.  Leaving out the tap correction in those four and the z correction in K-steps 0 and 8 costs,
+// whatever the input (|z| <= 8.25 * 0.9, worst output row, every rounding at its bound and aligned),
+//     |z|max * (sum |Alo| over the skipped taps of a row  +  2^-10 * sum |Ahi| over K-steps 0 and 8 of a row)
+//         = 2.4e-6 + 4.7e-6 = 7.1e-6 of full scale   (half-symbol phase: 3.7e-6 + 4.6e-6 = 8.3e-6)
+// with the shipped taps' own remainders (scripts/fir_error_budget.py), on top of 4e-7 of accumulation error: inside the 1e-5
+// the path is held to, by construction; measured 1.5e-6 at 64 x 64 fields.  It saves 6 of the tile's 27 MFMAs -- the kernel
+// runs at the board's power cap, where time follows energy.  Skipping the z correction in K-steps 1 and 7 as
+// well (19 MFMAs, another 2 % faster) has a worst case of 1.8e-5 and was not taken.
+constexpr bool tap_lo_needed(int ks) { return ks >= 2 && ks <= 6; }
+constexpr bool z_lo_needed(int ks) { return ks >= 1 && ks <= 7; }
+constexpr int products_of(int ks) { return 1 + (tap_lo_needed(ks) ? 1 : 0) + (z_lo_needed(ks) ? 1 : 0); }
+constexpr int steps_in(int ks, int first, int last) { return ks <= first ? 0 : (ks > last ? last - first + 1 : ks - first); }
+constexpr int chain_before(int ks) {   // MFMAs of one output phase in front of K-step ks
+    return ks + steps_in(ks, 2, 6) + steps_in(ks, 1, 7);
+}
+static_assert(chain_before(kKSteps) == 21 && chain_before(2) == 3, "21 MFMAs per tile and phase");
+
 template <int FMT, bool FUSED, int UP>
 __global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(const FirArgs a) {
     typedef Geo<FMT, UP> G;
@@ -517,9 +538,11 @@ __global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(con
             const __amdgpu_buffer_rsrc_t rs_iq = __builtin_amdgcn_make_buffer_rsrc(iq_base, 0, prev_ok ? iq_records : 0, kRsrcFlags);
             const int st_soff = (tile - 1) * G::kRowBytes;
             // chain slots of the tile's side work (UP = 1: the numbers the comments of side() name)
-            constexpr int kChain = 27 * UP;              // MFMAs per tile
-            constexpr int kMixAt = 6 * UP;               // K-steps 0 and 1 have issued: their slots take the next tile's
-            constexpr int kImgAt = kMixAt + 8;           // image writes, 4 values per slot
+            constexpr int kChain = chain_before(kKSteps) * UP;   // MFMAs per tile
+            // (same-box A/B of the placements, 1x output: mix at 4: 1.94-1.95 ms, at 3: 1.97, at 6: 1.96; at 5, or at 6 / 7 with other
+            // gaps: 2.67 -- hipcc's register allocation falls over; 27-MFMA chain with its own best placement: 2.00)
+            constexpr int kMixAt = 4 * UP;               // K-steps 0 and 1 have issued: their slots take the next tile's
+            constexpr int kImgAt = kMixAt + 4;           // image writes, 4 values per slot
             constexpr int kRdAt = kImgAt + 4 * UP;       // image reads, then the stores two slots behind
             static_assert(kRdAt + 2 + G::kStores <= kChain, "side work fits the chain");
             float y[16 * UP];
@@ -598,13 +621,17 @@ __global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(con
 #pragma unroll
                 for (int ph = 0; ph < UP; ++ph) {
                     const h8 ah = ahi[ph][ks], al = alo[ph][ks];
-                    const int i0 = 3 * (UP * ks + ph);
+                    int i = UP * chain_before(ks) + ph * products_of(ks);
                     acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ph], 0, 0, 0);
-                    side(i0);
-                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph], 0, 0, 0);
-                    side(i0 + 1);
-                    acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph], 0, 0, 0);
-                    side(i0 + 2);
+                    side(i++);
+                    if (tap_lo_needed(ks)) {
+                        acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph], 0, 0, 0);
+                        side(i++);
+                    }
+                    if (z_lo_needed(ks)) {
+                        acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph], 0, 0, 0);
+                        side(i++);
+                    }
                 }
             }
 #pragma unroll

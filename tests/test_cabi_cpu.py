@@ -135,3 +135,16 @@ def test_reference_caller_builds_unchanged_on_the_adapter():
     if not torch.cuda.is_available():
         run = subprocess.run([exe, "/dev/null"], capture_output=True, text=True)
         assert run.returncode != 0 and "no HIP device" in run.stderr     # loud, no CPU fallback
+
+
+def test_fir_low_order_products_left_out_stay_inside_the_tolerance():
+    """k_mix_fir_mm leaves the tap correction out of K-steps 0, 1, 7, 8 and the z correction out of K-steps 0 and 8
+    (fir_fused.hip: tap_lo_needed / z_lo_needed).  With the shipped taps' own fp16 remainders the worst case over every
+    input is below the path's 1e-5 of full scale, with room for the 5e-7 of accumulation error measured before."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fir_error_budget", os.path.join(ROOT, "scripts", "fir_error_budget.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for table, n in ((0, 111), (7, 112)):
+        total, _, _ = mod.budget(table, n, (0, 1, 7, 8), (0, 8))
+        assert total < 1e-5 - 1e-6, total
