@@ -18,7 +18,7 @@
 // registers: a tile converts only its 32 newest inputs per column, the rest is a renaming (the tile loop is unrolled
 // by nine).  What the previous form of this kernel spent per 16 outputs x 32 channels on regenerating its weights
 // (160 vector instructions: the oscillator was folded into the A operand) is gone; per 32 outputs x 16 channels a wave
-// now issues 27 MFMAs and ~50 vector instructions for the operands.
+// now issues 21 MFMAs (27 products less the low-order ones of the outer K-steps) and ~50 vector instructions for the operands.
 //
 // One wave = one (field, run of tiles, group of 16 channels) task:
 //   * symbols reach the wave through a wave-private LDS ring [16 channels][512 positions], stored as v << 5 so that a
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(con
             // Three things run in this tile's body, interleaved by hand so that the vector and LDS work sits between the
             // MFMAs of the chain instead of in front of and behind it (hipcc clusters them otherwise, and the two waves of a
             // SIMD then serialise on the phases):
-            //   chain : the 27 MFMAs of THIS tile
+            //   chain : the 21 MFMAs of THIS tile
             //   out   : the PREVIOUS tile's accumulator -> scale -> line image -> stores
             //   next  : the NEXT tile's two newest K-steps (its 32 newest inputs per column) -> the slots this tile's
             //           K-steps 0 and 1 vacate
