@@ -350,28 +350,42 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
 // {Th(2m), Th(2m+1)}, {Tl(2m), Tl(2m+1)} with Th = fl16(T * 4096), Tl = fl16(T * 4096 - Th).
 __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in, float2* __restrict__ tab,
                                                    float2* __restrict__ out, float2 sc, int fields, int planes) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kPaddedSyms) return;
-    float2 t = in[i];
+    // a thread owns two neighbouring table entries: the plane form packs their fp16 pieces into whole dwords (dword 2m of a
+    // plane = the two high pieces, dword 2m + 1 the two low ones), so it leaves as one 8-byte store per component and field
+    // instead of four 2-byte ones per entry; the complex form as one 16-byte store
+    static_assert(kPaddedSyms % 2 == 0, "entries come in pairs");
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= kPaddedSyms / 2) return;
+    const float4 t01 = reinterpret_cast<const float4*>(in)[m];
+    float2 t[2] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w)};
     float* pl = reinterpret_cast<float*>(tab);
     for (int f = 0; f < fields; ++f) {
         if (planes) {
-            _Float16* ph = reinterpret_cast<_Float16*>(pl + ((size_t)f * 2) * kPaddedSyms + (i & ~1)) + (i & 1);
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float v = (c ? t.y : t.x) * 4096.0f;
-                const _Float16 hi = (_Float16)v;
-                ph[(size_t)c * 2 * kPaddedSyms] = hi;                                  // dword 2m of plane c, half i & 1
-                ph[(size_t)c * 2 * kPaddedSyms + 2] = (_Float16)(v - (float)hi);       // dword 2m + 1
+                _Float16 hi[2], lo[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v = (c ? t[j].y : t[j].x) * 4096.0f;
+                    hi[j] = (_Float16)v;
+                    lo[j] = (_Float16)(v - (float)hi[j]);
+                }
+                uint2 w;
+                w.x = (uint32_t)__builtin_bit_cast(uint16_t, hi[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, hi[1]) << 16);
+                w.y = (uint32_t)__builtin_bit_cast(uint16_t, lo[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, lo[1]) << 16);
+                *reinterpret_cast<uint2*>(pl + ((size_t)f * 2 + c) * kPaddedSyms + 2 * m) = w;
             }
         } else {
-            tab[(size_t)f * kPaddedSyms + i] = t;
+            reinterpret_cast<float4*>(tab + (size_t)f * kPaddedSyms)[m] = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
         }
-        const float t2 = __fmul_rn(t.y, sc.y);
-        const float t3 = __fmul_rn(t.x, sc.y);
-        t = make_float2(__fmaf_rn(t.x, sc.x, -t2), __fmaf_rn(t.y, sc.x, t3));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float t2 = __fmul_rn(t[j].y, sc.y);
+            const float t3 = __fmul_rn(t[j].x, sc.y);
+            t[j] = make_float2(__fmaf_rn(t[j].x, sc.x, -t2), __fmaf_rn(t[j].y, sc.x, t3));
+        }
     }
-    out[i] = t;
+    reinterpret_cast<float4*>(out)[m] = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
 }
 
 hipError_t upload_fft_tables(const float* taps112) {
@@ -405,7 +419,7 @@ hipError_t upload_fft_tables(const float* taps112) {
 
 void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields,
                       bool planes) {
-    hipLaunchKernelGGL(k_osc_table, dim3((kPaddedSyms + 255) / 256), dim3(256), 0, s, osc_in, osc_tab, osc_out, scale,
+    hipLaunchKernelGGL(k_osc_table, dim3((kPaddedSyms / 2 + 255) / 256), dim3(256), 0, s, osc_in, osc_tab, osc_out, scale,
                        fields, planes ? 1 : 0);
 }
 
