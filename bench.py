@@ -446,8 +446,9 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         "metric": METRIC, "value": round(msym_s, 2), "unit": "Msym/s", "n_gpus": rk.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (oscillator, mixer products and accumulation in fp32; the FIR's multiplies run on the matrix cores "
-                  "with each fp32 operand split into two fp16 pieces, >= 21 significant bits)" if fused else "f32"),
+        "dtype": ("f32 (oscillator recursion and accumulation in fp32; the mixer product and the FIR's multiplies run on two "
+                  "fp16 pieces of each fp32 operand, matrix cores; the low-order pieces are left out for the outermost taps: "
+                  "1.5e-6 of full scale measured, 7.1e-6 worst case by construction, tolerance 1e-5)" if fused else "f32"),
         "data": "synthetic",
         "config": {"workload": f"{C_} channels x {F} fields per GPU per step (BASELINE config 4 per-GPU shard), "
                                f"TS resident in HBM, {'symbol tap + ' if args.symbol_tap else ''}"
