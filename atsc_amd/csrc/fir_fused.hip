@@ -621,16 +621,19 @@ __global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(con
 #pragma unroll
                 for (int ph = 0; ph < UP; ++ph) {
                     const h8 ah = ahi[ph][ks], al = alo[ph][ks];
-                    int i = UP * chain_before(ks) + ph * products_of(ks);
+                    // (the slot numbers are written as constants of the unrolled loop variables: with a running counter hipcc
+                    // no longer sees side()'s small arrays as registers and moves one of them into LDS, 12 KB and four extra
+                    // 16-byte LDS accesses per tile)
+                    const int i0 = UP * chain_before(ks) + ph * products_of(ks);
                     acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[ph], 0, 0, 0);
-                    side(i++);
+                    side(i0);
                     if (tap_lo_needed(ks)) {
                         acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[ph], 0, 0, 0);
-                        side(i++);
+                        side(i0 + 1);
                     }
                     if (z_lo_needed(ks)) {
                         acc[ph] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[ph], 0, 0, 0);
-                        side(i++);
+                        side(i0 + (tap_lo_needed(ks) ? 2 : 1));
                     }
                 }
             }
