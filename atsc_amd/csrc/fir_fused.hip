@@ -539,8 +539,8 @@ __global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(con
             const int st_soff = (tile - 1) * G::kRowBytes;
             // chain slots of the tile's side work (UP = 1: the numbers the comments of side() name)
             constexpr int kChain = chain_before(kKSteps) * UP;   // MFMAs per tile
-            // (same-box A/B of the placements, 1x output: mix at 4: 1.94-1.95 ms, at 3: 1.97, at 6: 1.96; at 5, or at 6 / 7 with other
-            // gaps: 2.67 -- hipcc's register allocation falls over; 27-MFMA chain with its own best placement: 2.00)
+            // (same-box A/B of ten placements -- mix at 3..7, image 4..6 slots behind it, image reads 0..2 slots later: all within
+            // 1 %, 1.90-1.92 ms; the 27-MFMA chain with its own best placement: 2.00)
             constexpr int kMixAt = 4 * UP;               // K-steps 0 and 1 have issued: their slots take the next tile's
             constexpr int kImgAt = kMixAt + 4;           // image writes, 4 values per slot
             constexpr int kRdAt = kImgAt + 4 * UP;       // image reads, then the stores two slots behind
