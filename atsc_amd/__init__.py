@@ -33,7 +33,7 @@ STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trell
 # every symbol include/atsc_hip.h declares
 EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_encode_batch",
            "atsc_hip_encode_begin", "atsc_hip_encode_finish",
-           "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_mix_fir_static", "atsc_hip_export_state", "atsc_hip_import_state",
+           "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_mix_fir_static", "atsc_hip_export_state", "atsc_hip_import_state", "atsc_hip_seek",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
            "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form", "atsc_hip_set_upsample", "atsc_hip_get_upsample",
            "atsc_hip_process_chunked",
@@ -105,6 +105,7 @@ def load_library():
     L.atsc_hip_mix_fir_static.argtypes = [C.c_int, u8p, C.c_int, C.c_int, C.c_uint64, vp, C.c_int, vp]
     L.atsc_hip_export_state.argtypes = [vp, C.c_int, C.POINTER(StreamState)]
     L.atsc_hip_import_state.argtypes = [vp, C.c_int, C.POINTER(StreamState)]
+    L.atsc_hip_seek.argtypes = [vp, C.c_uint64, vp]
     L.atsc_hip_span_parity.argtypes = [vp, C.c_int, u8p]
     L.atsc_hip_stage_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.atsc_hip_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
@@ -248,6 +249,10 @@ class Encoder:
 
     def import_state(self, st, channel=0):
         check(self.L.atsc_hip_import_state(self.h, channel, C.byref(st)))
+
+    def seek(self, field_index, stream=None):
+        """atsc_hip_seek: every channel starts at absolute field `field_index` with zero trellis state, in stream order."""
+        check(self.L.atsc_hip_seek(self.h, field_index, stream))
 
     def span_parity(self, channel=0):
         import numpy as np

@@ -35,6 +35,7 @@ struct atsc_hip_encoder {
     uint8_t* d_sym = nullptr;   // internal symbol buffer [channels][max_fields][260416]
     size_t sym_stride = 0;
     float2* d_osc[2] = {nullptr, nullptr};
+    float2* d_osc0 = nullptr;     // T_0, read-only after create (atsc_hip_seek)
     float2* d_osc_tab = nullptr;  // [max_fields][261248] oscillator table of the current batch
     int osc_cur = 0;
     float2 scale{};
@@ -89,7 +90,7 @@ static int destroy_impl(atsc_hip_encoder* e) {
     hipSetDevice(e->cfg.device);
     hipFree(e->buf.coded); hipFree(e->buf.tail); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
     hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
-    hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc_tab); hipFree(e->d_tables);
+    hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc0); hipFree(e->d_osc_tab); hipFree(e->d_tables);
     for (auto& sl : e->slot) {
         hipFree(sl.d_ts); hipFree(sl.d_iq);
         if (sl.h_ts) hipHostFree(sl.h_ts);
@@ -203,6 +204,8 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     // oscillator state (double-buffered), T_0 and the per-field rotation
     for (int i = 0; i < 2; ++i) TRY_OR_FREE(hipMalloc(&e->d_osc[i], sizeof(float2) * kPaddedSyms));
     TRY_OR_FREE(hipMemcpy(e->d_osc[0], e->tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice));
+    TRY_OR_FREE(hipMalloc(&e->d_osc0, sizeof(float2) * kPaddedSyms));
+    TRY_OR_FREE(hipMemcpy(e->d_osc0, e->tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice));
     TRY_OR_FREE(hipMalloc(&e->d_osc_tab, sizeof(float2) * (kPaddedSyms * F + kOscTabSlack)));
     e->scale = make_float2(e->tab.scale[0], e->tab.scale[1]);
 
@@ -660,6 +663,38 @@ extern "C" int atsc_hip_import_state(atsc_hip_encoder* e, int channel, const ats
         HIP_TRY(hipDeviceSynchronize());
         e->osc_cur = src;
         e->field_index = in->field_index;
+    }
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_seek(atsc_hip_encoder* e, uint64_t field_index, void* stream) {
+    if (!e) return ATSC_HIP_ERR_ARG;
+    if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    auto s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(e->buf.carry, 0, sizeof(uint4) * e->cfg.channels, s));
+    if (field_index != e->field_index) {
+        // T_f = T_(f-1) (x) scale, sequentially in fp32 (offset.h:35-41): the handle's state IS T_(its field index) of that
+        // sequence, so a target ahead of it is reached from there; one behind it from the device copy of T_0
+        const float2* from = e->d_osc[e->osc_cur];
+        uint64_t left = field_index;
+        if (field_index > e->field_index) left = field_index - e->field_index;
+        else from = e->d_osc0;
+        int dst = e->osc_cur ^ 1;
+        if (left == 0) {
+            HIP_TRY(hipMemcpyAsync(e->d_osc[dst], from, sizeof(float2) * kPaddedSyms, hipMemcpyDeviceToDevice, s));
+        } else {
+            while (left > 0) {
+                const unsigned n = (unsigned)std::min<uint64_t>(left, 1u << 20);
+                launch_osc_advance(s, from, e->d_osc[dst], e->scale, n);
+                from = e->d_osc[dst];
+                left -= n;
+                if (left) dst ^= 1;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        e->osc_cur = dst;
+        e->field_index = field_index;
     }
     return ATSC_HIP_OK;
 }

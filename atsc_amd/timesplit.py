@@ -90,12 +90,9 @@ class TimeSplitEncoder:
         stream = torch.cuda.current_stream().cuda_stream
         # warm-up field: leaves the right interleaver tail and last interleaved group in the handle
         self.enc.encode_batch(halo_field_ts.data_ptr(), 1, None, None, stream)
-        for c in range(self.channels):
-            st = self.enc.export_state(c)
-            for i in range(12):                  # trellis state comes from the exchange, not from the halo
-                st.z2[i] = st.z0_next[i] = st.z0_prev[i] = 0
-            st.field_index = first_field         # field parity + oscillator phase of the span start
-            self.enc.import_state(st, c)
+        # trellis state comes from the exchange, not from the halo; field parity + oscillator phase of the span start.
+        # All channels at once, on the device, in stream order (no host round trip)
+        self.enc.seek(first_field, stream)
 
     def encode(self, d_ts, d_sym, d_iq, group=None, exchange=exclusive_xor_over_ranks):
         """begin -> exchange span parities -> finish.  d_ts/d_sym/d_iq: device tensors of this span

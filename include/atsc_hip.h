@@ -218,6 +218,18 @@ int atsc_hip_export_state(atsc_hip_encoder* enc, int channel, atsc_hip_stream_st
  * oscillator table T_f = T_0 (x) scale^f by the reference's fp32 recursion when it changes. */
 int atsc_hip_import_state(atsc_hip_encoder* enc, int channel, const atsc_hip_stream_state* in);
 
+/* Re-seat EVERY channel of the handle at absolute field `field_index` with a zero trellis / precoder state, on the device
+ * and in stream order: no host round trip, no synchronisation.  The interleaver history the handle holds (coded tail, last
+ * interleaved group: what the previous batch left) stays; the field parity follows the index and the oscillator state
+ * becomes T_field_index by the reference's own fp32 recursion (offset.h:35-41: advanced from the handle's current state
+ * when field_index lies ahead of it, from T_0 otherwise -- the same sequence of roundings either way).
+ * This is the time-split's "start a span here" (SURVEY.md 8e): encode the one-field halo, seek to the span's first field,
+ * then atsc_hip_encode_begin / _finish with the carry of the earlier spans.  It does for all channels at once what an
+ * atsc_hip_export_state / atsc_hip_import_state pair per channel did through the host.  No reference counterpart: the
+ * reference cannot start mid-stream (atsc.cpp:34-40 zero state only).
+ * Returns ATSC_HIP_ERR_STATE between atsc_hip_encode_begin and _finish. */
+int atsc_hip_seek(atsc_hip_encoder* enc, uint64_t field_index, void* stream);
+
 /* Trellis parity of a span of fields encoded from zero trellis state: out36[0..11]=z2, [12..23]=z0_next,
  * [24..35]=z0_prev contribution.  state_out = state_in XOR span_parity.  Valid after a batch. */
 int atsc_hip_span_parity(atsc_hip_encoder* enc, int channel, uint8_t* out36);

@@ -261,3 +261,50 @@ def test_matrix_core_forms_respect_the_descriptor_limit():
     e = atsc_amd.Encoder(channels=16, max_fields=128)
     assert e.fir_form() == atsc_amd.FIR_FUSED
     e.close()
+
+
+def test_seek_equals_the_export_import_route(torch_cuda):
+    """atsc_hip_seek (all channels, on the device, stream-ordered) against what it replaces: per channel
+    export_state -> zero the trellis state, set the field index -> import_state through the host.  After a halo field both
+    handles encode the same span with the same carry: symbols and IQ bit-identical, for a target ahead of the handle's
+    field index (oscillator advanced from its current state), one behind it (from T_0), the index it already has and 0."""
+    torch = torch_cuda
+    C_, nf = 3, 2
+    st = torch.cuda.current_stream().cuda_stream
+    ts = _streams(torch, C_, 1 + nf, 77)
+    halo, span = ts[:, 0].contiguous(), ts[:, 1:].contiguous()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    carry = torch.randint(0, 8, (4 * C_, 4), dtype=torch.uint8, device="cuda", generator=g)
+    carry[3::4] = 0                                       # the pad word of every channel
+    carry = carry.view(torch.int32).view(-1).contiguous()
+    a = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    b = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    for target in (40, 3, 3, 1, 0, 1000):                 # ahead, behind, same, ..., far ahead
+        outs = []
+        for enc, use_seek in ((a, True), (b, False)):
+            enc.encode_batch(halo.data_ptr(), 1, None, None, st)
+            if use_seek:
+                enc.seek(target, st)
+            else:
+                for c in range(C_):
+                    s = enc.export_state(c)
+                    for i in range(12):
+                        s.z2[i] = s.z0_next[i] = s.z0_prev[i] = 0
+                    s.field_index = target
+                    enc.import_state(s, c)
+            d_sym = torch.empty(C_ * nf * FIELD_SYMBOLS, dtype=torch.uint8, device="cuda")
+            d_iq = torch.empty(C_ * nf * FIELD_SYMBOLS, dtype=torch.complex64, device="cuda")
+            par = torch.zeros(4 * C_, dtype=torch.int32, device="cuda")
+            enc.encode_begin(span.data_ptr(), nf, par.data_ptr(), st)
+            if use_seek:
+                with pytest.raises(atsc_amd.AtscHipError) as ei:
+                    enc.seek(target + 1, st)              # not between begin and finish
+                assert ei.value.code == atsc_amd.ERR_STATE
+            enc.encode_finish(carry.data_ptr(), d_sym.data_ptr(), d_iq.data_ptr(), st)
+            torch.cuda.synchronize()
+            outs.append((d_sym, torch.view_as_real(d_iq).view(torch.int32), par))
+        assert bool((outs[0][0] == outs[1][0]).all()), f"target {target}: symbols differ"
+        assert bool((outs[0][1] == outs[1][1]).all()), f"target {target}: IQ bits differ"
+        assert bool((outs[0][2] == outs[1][2]).all())
+        assert a.export_state(0).field_index == target + nf
