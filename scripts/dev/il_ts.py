@@ -1,5 +1,10 @@
 #!/usr/bin/env python3
-"""Phase timestamps of one k_interleave workgroup (variant build il_ts; GPU box).  Prints mean cycles per phase per wave."""
+"""Phase timestamps of one k_interleave workgroup (GPU box).  Prints mean cycles per phase per wave.
+
+Needs a variant library build/var/il_ts (scripts/dev/variant.sh il_ts "" kernels.hip <copy>) from a COPY of kernels.hip in which
+one workgroup (blockIdx (3, 5), chunks 8..40) writes __builtin_readcyclecounter() at the phase boundaries of chunk() into the
+front of the `par` buffer, [chunk][wave][8 stamps] as uint64: the instrumented copy is not kept in the tree (it is the kernel
+plus seven stores); DESIGN.md 3 (k_interleave) quotes what it showed."""
 import ctypes, os, sys
 import numpy as np
 import torch
