@@ -25,6 +25,8 @@ SYMBOL_RATE = 4500000.0 / 286 * 684  # 10.762238 MHz, one real-time channel
 
 FLAG_TIMING = 1
 FLAG_TAPS = 2
+FLAG_STRICT_FP32 = 4
+MAX_SEEK_STEPS = 1 << 24
 (STAGE_RAND_RS, STAGE_INTERLEAVE, STAGE_TRELLIS_PAR, STAGE_TRELLIS_SCAN, STAGE_TRELLIS_MAP, STAGE_OSC, STAGE_MIX_FIR,
  STAGE_STATE, NSTAGES) = range(9)
 STAGE_NAMES = ("rand_rs", "interleave", "trellis_parity", "trellis_scan", "trellis_map", "osc_table", "mix_fir",
@@ -162,10 +164,11 @@ class Encoder:
     (ints, e.g. ``tensor.data_ptr()``) and is asynchronous on ``stream``.
     """
 
-    def __init__(self, channels=1, max_fields=1, device=0, timing=False, taps=False):
+    def __init__(self, channels=1, max_fields=1, device=0, timing=False, taps=False, strict_fp32=False):
         self.L = load_library()
         self.channels, self.max_fields, self.device = channels, max_fields, device
-        cfg = Config(device, channels, max_fields, (FLAG_TIMING if timing else 0) | (FLAG_TAPS if taps else 0))
+        cfg = Config(device, channels, max_fields, (FLAG_TIMING if timing else 0) | (FLAG_TAPS if taps else 0)
+                     | (FLAG_STRICT_FP32 if strict_fp32 else 0))
         h = C.c_void_p()
         check(self.L.atsc_hip_create(C.byref(cfg), C.byref(h)))
         self.h = h

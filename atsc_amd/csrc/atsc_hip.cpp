@@ -60,6 +60,8 @@ struct atsc_hip_encoder {
         hipEvent_t copied = nullptr;     // IQ of the slot's batch in h_iq (copy stream)
     } slot[2];
     hipStream_t compute_stream = nullptr, copy_stream = nullptr;
+    hipStream_t last_stream = nullptr;   // the stream the handle's state was last touched on (batch calls, seek)
+    hipEvent_t order_ev = nullptr;       // orders atsc_hip_process's private streams behind it
 
     // timing: a ring of event sets, one per batch, so a timed region can be read back afterwards
     struct EventSet {
@@ -98,6 +100,7 @@ static int destroy_impl(atsc_hip_encoder* e) {
         if (sl.encoded) hipEventDestroy(sl.encoded);
         if (sl.copied) hipEventDestroy(sl.copied);
     }
+    if (e->order_ev) hipEventDestroy(e->order_ev);
     if (e->compute_stream) hipStreamDestroy(e->compute_stream);
     if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     for (auto& set : e->slots)
@@ -193,7 +196,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     TRY_OR_FREE(hipMalloc(&e->buf.carry, C * sizeof(uint4)));
     TRY_OR_FREE(hipMalloc(&e->buf.span_par, C * sizeof(uint4)));
     TRY_OR_FREE(hipMalloc(&e->buf.last_group, C * 16));
-    TRY_OR_FREE(hipMalloc(&e->d_sym, C * e->sym_stride));
+    // (the internal symbol buffer [C][F][260416] is allocated by the first batch that needs it: the fused form never does)
     // zero history (reference: atsc.cpp:24-26,34; trellis.h:55-59)
     if (e->buf.coded) TRY_OR_FREE(hipMemset(e->buf.coded, 0, C * e->buf.coded_stride));
     TRY_OR_FREE(hipMemset(e->buf.tail, 0, C * kTail));
@@ -289,6 +292,7 @@ bool matrix_forms_fit(const atsc_hip_encoder* e, int iq_format, int upsample) {
 
 int resolve_fir_form(const atsc_hip_encoder* e) {
     if (e->fir_form != ATSC_HIP_FIR_AUTO) return e->fir_form;
+    if (e->cfg.flags & ATSC_HIP_FLAG_STRICT_FP32) return ATSC_HIP_FIR_FFT;   // (set_upsample(2) is refused on such a handle)
     if (e->upsample != 1) return ATSC_HIP_FIR_FUSED;   // only the matrix-core kernel interpolates (set_upsample checked that it fits)
     if (!matrix_forms_fit(e, e->iq_format, 1)) return ATSC_HIP_FIR_FFT;
     // The fused kernel works on groups of kFusedGroup channels and costs the same for a partly filled group, the FFT
@@ -324,6 +328,14 @@ int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, vo
 
 }  // namespace
 
+// The internal symbol buffer, on first use: only the separate-kernel forms called without a caller buffer write it (1 GiB at
+// 64 channels x 64 fields that the fused form would hold for nothing).
+static int ensure_sym_buffer(atsc_hip_encoder* e) {
+    if (e->d_sym) return ATSC_HIP_OK;
+    HIP_TRY(hipMalloc(&e->d_sym, (size_t)e->cfg.channels * e->sym_stride));
+    return ATSC_HIP_OK;
+}
+
 static int check_batch_args(atsc_hip_encoder* e, const void* d_ts, int fields, const void* d_sym, const void* d_iq) {
     if (!e || !d_ts || fields < 1) return ATSC_HIP_ERR_ARG;
     if (fields > e->cfg.max_fields) return ATSC_HIP_ERR_TOO_LARGE;
@@ -342,6 +354,7 @@ extern "C" int atsc_hip_encode_begin(atsc_hip_encoder* e, const uint8_t* d_ts, i
     auto s = static_cast<hipStream_t>(stream);
     begin_batch_timing(e);
     e->last_fields = fields;
+    e->last_stream = s;
     rc = run_front(e, d_ts, fields, s);
     if (rc) return rc;
     if (d_span_parity) launch_span_parity(s, e->buf, static_cast<uint4*>(d_span_parity), e->cfg.channels, fields);
@@ -353,11 +366,17 @@ extern "C" int atsc_hip_encode_begin(atsc_hip_encoder* e, const uint8_t* d_ts, i
 // state (interleaver tail, carries, oscillator) may have been advanced part of the way: undefined until
 // atsc_hip_import_state re-seats it (include/atsc_hip.h).
 static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_sym, void* d_iq, hipStream_t s, int fields) {
-    uint8_t* sym = d_sym ? d_sym : e->d_sym;
     e->last_fields = fields;
+    e->last_stream = s;
     const size_t sym_stride = (size_t)fields * kFieldSyms;
     int rc;
-    if (d_iq && resolve_fir_form(e) == ATSC_HIP_FIR_FUSED) {
+    const bool fused = d_iq && resolve_fir_form(e) == ATSC_HIP_FIR_FUSED;
+    if (!fused && !d_sym) {
+        rc = ensure_sym_buffer(e);
+        if (rc) return rc;
+    }
+    uint8_t* sym = d_sym ? d_sym : e->d_sym;
+    if (fused) {
         // carries, then ONE kernel for trellis / map / sync / mixer / FIR: the symbols never pass through HBM; the symbol
         // tap is written only if the caller asked for it (d_sym)
         mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);
@@ -416,6 +435,7 @@ extern "C" int atsc_hip_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, int f
     HIP_TRY(hipSetDevice(e->cfg.device));
     auto s = static_cast<hipStream_t>(stream);
     begin_batch_timing(e);
+    e->last_stream = s;
     int rc = run_mix_fir(e, d_sym, (size_t)fields * kFieldSyms, d_iq, fields, s);
     mark(e, s, ATSC_HIP_STAGE_STATE);
     if (rc) return rc;
@@ -461,6 +481,7 @@ extern "C" size_t atsc_hip_iq_sample_bytes(int format) {
 extern "C" int atsc_hip_set_fir_form(atsc_hip_encoder* e, int form) {
     if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_FUSED) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if ((form == ATSC_HIP_FIR_MFMA || form == ATSC_HIP_FIR_FUSED) && (e->cfg.flags & ATSC_HIP_FLAG_STRICT_FP32)) return ATSC_HIP_ERR_ARG;
     if ((form == ATSC_HIP_FIR_MFMA || form == ATSC_HIP_FIR_FUSED) && !matrix_forms_fit(e, e->iq_format, e->upsample)) return ATSC_HIP_ERR_TOO_LARGE;
     if (form == ATSC_HIP_FIR_FFT && e->upsample != 1) return ATSC_HIP_ERR_ARG;   // the FFT form does not interpolate
     e->fir_form = form;
@@ -486,7 +507,7 @@ extern "C" int atsc_hip_set_upsample(atsc_hip_encoder* e, int factor) {
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
     if (factor == e->upsample) return ATSC_HIP_OK;
     if (factor == 2) {
-        if (e->fir_form == ATSC_HIP_FIR_FFT) return ATSC_HIP_ERR_ARG;
+        if (e->fir_form == ATSC_HIP_FIR_FFT || (e->cfg.flags & ATSC_HIP_FLAG_STRICT_FP32)) return ATSC_HIP_ERR_ARG;
         if (!matrix_forms_fit(e, e->iq_format, 2)) return ATSC_HIP_ERR_TOO_LARGE;
     }
     e->upsample = factor;
@@ -548,6 +569,13 @@ static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned cou
     HIP_TRY(hipSetDevice(e->cfg.device));
     int rc = streaming_setup(e);
     if (rc) return rc;
+    // The streaming path runs on private non-blocking streams: whatever the caller queued for this handle on another
+    // stream (atsc_hip_encode_batch, atsc_hip_seek) must have touched the tail / carry / oscillator buffers first
+    if (e->last_stream != e->compute_stream) {
+        if (!e->order_ev) HIP_TRY(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(e->order_ev, e->last_stream));
+        HIP_TRY(hipStreamWaitEvent(e->compute_stream, e->order_ev, 0));
+    }
     const size_t F = e->cfg.max_fields;
     const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
     const size_t field_samples = (size_t)kFieldSyms * e->upsample;
@@ -650,6 +678,7 @@ extern "C" int atsc_hip_import_state(atsc_hip_encoder* e, int channel, const ats
     }
     HIP_TRY(hipMemcpy(e->buf.carry + channel, cw, 16, hipMemcpyHostToDevice));
     if (in->field_index != e->field_index) {
+        if (in->field_index > ATSC_HIP_MAX_SEEK_STEPS) return ATSC_HIP_ERR_TOO_LARGE;
         // T_f = T_0 (x) scale^f by the reference's own sequential fp32 recursion (offset.h:35-41)
         HIP_TRY(hipMemcpy(e->d_osc[e->osc_cur ^ 1], e->tab.osc0.data(), sizeof(float2) * kPaddedSyms, hipMemcpyHostToDevice));
         uint64_t left = in->field_index;
@@ -670,16 +699,20 @@ extern "C" int atsc_hip_import_state(atsc_hip_encoder* e, int channel, const ats
 extern "C" int atsc_hip_seek(atsc_hip_encoder* e, uint64_t field_index, void* stream) {
     if (!e) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    // T_f = T_(f-1) (x) scale, sequentially in fp32 (offset.h:35-41): the handle's state IS T_(its field index) of that
+    // sequence, so a target ahead of it is reached from there; one behind it from the device copy of T_0.  The walk is
+    // one dependent step per field and lane: more than ATSC_HIP_MAX_SEEK_STEPS of them are refused (a garbage index would
+    // otherwise hang the stream for minutes)
+    const bool ahead = field_index >= e->field_index;
+    const uint64_t steps = ahead ? field_index - e->field_index : field_index;
+    if (steps > ATSC_HIP_MAX_SEEK_STEPS) return ATSC_HIP_ERR_TOO_LARGE;
     HIP_TRY(hipSetDevice(e->cfg.device));
     auto s = static_cast<hipStream_t>(stream);
     HIP_TRY(hipMemsetAsync(e->buf.carry, 0, sizeof(uint4) * e->cfg.channels, s));
+    e->last_stream = s;
     if (field_index != e->field_index) {
-        // T_f = T_(f-1) (x) scale, sequentially in fp32 (offset.h:35-41): the handle's state IS T_(its field index) of that
-        // sequence, so a target ahead of it is reached from there; one behind it from the device copy of T_0
-        const float2* from = e->d_osc[e->osc_cur];
-        uint64_t left = field_index;
-        if (field_index > e->field_index) left = field_index - e->field_index;
-        else from = e->d_osc0;
+        const float2* from = ahead ? e->d_osc[e->osc_cur] : e->d_osc0;
+        uint64_t left = steps;
         int dst = e->osc_cur ^ 1;
         if (left == 0) {
             HIP_TRY(hipMemcpyAsync(e->d_osc[dst], from, sizeof(float2) * kPaddedSyms, hipMemcpyDeviceToDevice, s));
@@ -692,7 +725,7 @@ extern "C" int atsc_hip_seek(atsc_hip_encoder* e, uint64_t field_index, void* st
                 if (left) dst ^= 1;
             }
         }
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipGetLastError());   // host state moves only when every launch was accepted
         e->osc_cur = dst;
         e->field_index = field_index;
     }

@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <new>
 
 #include "kernels.h"
@@ -39,17 +40,26 @@ constexpr size_t kScratchEntries = kOffTab + (size_t)kStaticMaxFields * kPaddedS
 static __device__ __align__(256) float2 scratch[kScratchEntries];
 
 struct DeviceSetup {
+    std::once_flag once;     // two host threads' first calls on a device run the set-up once
+    int rc = ATSC_HIP_ERR_STATE;
     float2* ptr = nullptr;   // this device's address of `scratch`
     float2 scale{};
-    bool ready = false;
 };
 DeviceSetup g_setup[kMaxDevices];
 
+// puts the caller's current device back on every way out of the entry point
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // Once per device, with that device current.  This is the only place that builds host tables and copies them over;
-// it must run outside a graph capture (call the entry point once with fields = 0 to force it).
-int setup_device(int device) {
-    DeviceSetup& d = g_setup[device];
-    if (d.ready) return ATSC_HIP_OK;
+// it must run outside a graph capture (call the entry point once with fields = 0 to force it).  It also launches one
+// kernel of every code object the entry point uses (kernels.hip: k_osc_advance; fir_fft.hip: k_osc_table, k_mix_fir_fft)
+// on scratch memory, so that the runtime's lazy module loading -- which allocates -- happens here and not in a later call
+// that may be under capture.
+int setup_device_once(DeviceSetup& d) {
     float2* p = nullptr;
     hipError_t e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
     if (e != hipSuccess) return static_cast<int>(e);
@@ -65,9 +75,25 @@ int setup_device(int device) {
     } catch (const std::bad_alloc&) {
         return static_cast<int>(hipErrorOutOfMemory);
     }
+    // module warm-up: one field of one channel, symbols read from the (initialised) T_0 bytes, IQ written into the slot of
+    // the batch table's third field; every result is overwritten by the first real call
+    launch_osc_advance(nullptr, p + kOffT0, p + kOffStateA, d.scale, 1);
+    launch_osc_table(nullptr, p + kOffStateA, p + kOffStateB, p + kOffTab, d.scale, 1, false);
+    for (int fmt : {ATSC_HIP_IQ_CF32, ATSC_HIP_IQ_CS16, ATSC_HIP_IQ_CS8})
+        launch_mix_fir_fft(nullptr, reinterpret_cast<const uint8_t*>(p + kOffT0), kFieldSyms, p + kOffTab + 2 * (size_t)kPaddedSyms,
+                           kFieldSyms, p + kOffTab, 1, 1, fmt);
+    e = hipGetLastError();
+    if (e != hipSuccess) return static_cast<int>(e);
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) return static_cast<int>(e);
     d.ptr = p;
-    d.ready = true;
     return ATSC_HIP_OK;
+}
+
+int setup_device(int device) {
+    DeviceSetup& d = g_setup[device];
+    std::call_once(d.once, [&] { d.rc = setup_device_once(d); });
+    return d.rc;   // a failed set-up stays failed for the process (the error code says why)
 }
 
 }  // namespace
@@ -77,10 +103,12 @@ extern "C" int atsc_hip_mix_fir_static(int device, const uint8_t* d_sym, int cha
     if (device < 0 || device >= kMaxDevices || channels < 1 || fields < 0) return ATSC_HIP_ERR_ARG;
     if (fields > kStaticMaxFields) return ATSC_HIP_ERR_TOO_LARGE;   // the batch table in `scratch` holds 4 fields
     if (!atsc_hip_iq_sample_bytes(iq_format)) return ATSC_HIP_ERR_ARG;
-    if (field_index > (uint64_t)1 << 24) return ATSC_HIP_ERR_TOO_LARGE;   // T_f is re-derived by f sequential steps per call
+    // T_f is re-derived by field_index sequential steps per call and lane: 2^24 of them are about a second of GPU time
+    if (field_index > ATSC_HIP_MAX_SEEK_STEPS) return ATSC_HIP_ERR_TOO_LARGE;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ATSC_HIP_ERR_NO_DEVICE;
     if (device >= ndev) return ATSC_HIP_ERR_ARG;
+    DeviceRestore restore;   // the caller's current device is put back when the call returns
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return static_cast<int>(e);
     const int rc = setup_device(device);

@@ -42,8 +42,35 @@ SYMBOL_RATE_MSPS = 4500000.0 / 286 * 684 / 1e6  # 10.762238 Msym/s = one real-ti
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 CHAIN_BYTES_PER_SYM = 8.225    # whole chain fused minimum (58656 B in + 2083328 B out per field)
 FIELD_SYMBOLS = 313 * 832
+FUSED_DTYPE = ("f32 (oscillator recursion and accumulation in fp32; the mixer product and the FIR's multiplies run on two "
+               "fp16 pieces of each fp32 operand, matrix cores; the low-order pieces are left out for the outermost taps: "
+               "1.5e-6 of full scale measured, 7.1e-6 worst case by construction, tolerance 1e-5)")
 METRIC = "real-time ATSC channels per GPU (Msym/s; 10.76=1 ch) at 1/2/4/8 MI355X"
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_ROUND = "r03"
+PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
+KERNEL_SOURCES = ("kernels.hip", "fir_fft.hip", "fir_fused.hip", "fir_w.hip", "resample.hip", "static_entry.hip", "kernels.h",
+                  "trellis_bits.h", "iq_format.h")
+
+
+def kernel_sources_hash():
+    """sha256 over the device sources of the product library (what a committed profile was taken from)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        path = os.path.join(ROOT, "atsc_amd", "csrc", name)
+        if os.path.exists(path):
+            h.update(name.encode() + b"\0" + open(path, "rb").read())
+    return h.hexdigest()
+
+
+def kernel_sources_changed_since_profile():
+    """True / False against profiles/rNN/kernel_sources.sha256 (written by scripts/summarize_profile.py when the counter
+    passes are summarised); None when the round has no committed profile yet."""
+    try:
+        stored = open(os.path.join(PROFILE_DIR, "kernel_sources.sha256")).read().split()[0]
+    except (OSError, IndexError):
+        return None
+    return stored != kernel_sources_hash()
 
 
 def host_cores():
@@ -130,6 +157,13 @@ def parse_args(argv=None):
     ap.add_argument("--upsample", type=int, choices=(1, 2), default=1,
                     help="SURVEY 8f-1: 2 = the interpolating form of the filter (atsc_hip_set_upsample): two samples per symbol "
                          "out of the same pass, the even ones the reference's.  Not the headline configuration")
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="after the headline loop: this many seconds of back-to-back steps, reported as `sustained` (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs behind the headline loop (sustained run, fp32-form run, in-run IQ error): profiler passes")
+    ap.add_argument("--rccl", action="store_true",
+                    help="run under this script's own launcher even with --gpus 1, so that the rank initialises an RCCL "
+                         "process group and the collectives really run (backend \"nccl\" in the line)")
     ap.add_argument("--cpu-stub", action="store_true",
                     help="CPU tests: launcher + gloo rendezvous + barrier/max-over-ranks plumbing with the GPU step stubbed")
     args = ap.parse_args(argv)
@@ -144,7 +178,10 @@ def launch_ranks(args, argv):
     n = args.gpus
     if not args.cpu_stub:
         import torch
-        have = torch.cuda.device_count()   # counting devices does not initialise the GPU runtime
+        # (on this image torch counts devices through amdsmi when it is importable and falls back to hipGetDeviceCount,
+        # which does initialise the runtime in THIS process; either way this process starts no GPU work and the ranks are
+        # fresh children)
+        have = torch.cuda.device_count()
         if have < n:
             sys.stderr.write(f"bench.py: --gpus {n} but only {have} GPU(s) are visible: refusing to report a "
                              f"{n}-GPU number from fewer devices\n")
@@ -331,19 +368,22 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world,
                          "achieved_gbs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
     stages["rand_rs"] = {"bound": "lds", "avg_launch_ms": round(stage_ms["rand_rs"], 4),
                          "gf256_mul_adds_per_launch": 3740 * 312 * C_ * F}
+    # figures replayed from the committed counter passes (the driver's run cannot run rocprofv3): kept under their own
+    # key, with the commit they were taken on and whether any kernel source has changed since
+    replayed = {"dir": f"profiles/{PROFILE_ROUND}", "kernel_sources_changed_since_profile": kernel_sources_changed_since_profile()}
     util = load_profile_json("utilisation.json")
     if util and util.get("workload") == f"{C_} channels x {F} fields":
-        for k, v in util.get("kernels", {}).items():
-            stages.setdefault(k, {}).update(v)
-        stages["_utilisation_source"] = {"file": "profiles/r02/utilisation.json", "commit": util.get("commit")}
+        replayed["utilisation"] = {"commit": util.get("commit"), "kernels": util.get("kernels", {})}
 
     traffic, traffic_src = None, None
     tj = load_profile_json("traffic.json")
     if tj and tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8 and up == 1 and \
             ("fused" in tj.get("kernel", "")) == fused:
         traffic = tj["traffic_bytes_per_launch"]
-        traffic_src = {"file": "profiles/r02/traffic.json", "commit": tj.get("commit"),
+        traffic_src = {"file": f"profiles/{PROFILE_ROUND}/traffic.json", "commit": tj.get("commit"), "kernel": tj.get("kernel"),
+                       "kernel_sources_changed_since_profile": replayed["kernel_sources_changed_since_profile"],
                        "note": "PMC passes of scripts/profile_gpu.sh (fetch, write) on the named commit, summarised by scripts/summarize_profile.py; not re-measured in this run"}
+    stages["_from_committed_profile"] = replayed
     roofline = {
         "kernel": ("k_mix_fir_mm<cf32, fused> (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes, "
                    "pilot + offset mixer first, then the 112-tap RRC FIR as Y = A.Z with a constant Toeplitz tap operand on the "
@@ -364,10 +404,28 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world,
                 "stream of this shape reaches 5.7 TB/s on this part, DESIGN.md)",
         "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes * up) * msym_s * 1e6 / world / 1e9, 1),
     }
-    err = load_profile_json("fused_iq_error.json")
-    if fused and err and up == 1:
-        roofline["iq_max_abs_error_vs_oracle"] = err
     return stage_ms, roofline, stages
+
+
+def iq_error_in_run(ts, first_iq, F):
+    """Max |IQ - checker| of this run's own first batch (zero history), for the kept channels: the compiled reference
+    when oracle/_ref travelled with the tree, else the C restatement.  The checker runs after the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    use_ref = ol.ref_available()
+    worst, per = 0.0, {}
+    t0 = time.perf_counter()
+    for c, got in first_iq.items():
+        h_ts = ts[c].reshape(-1).cpu().numpy()
+        want = (ol.Ref() if use_ref else ol.Oracle()).process_fields(h_ts, F, want=("iq",))["iq"]
+        e = float(np.abs(got - np.asarray(want, dtype=np.float32).reshape(-1)).max())
+        per[str(c)] = e
+        worst = max(worst, e)
+    return {"max_abs_error": worst, "per_channel": per, "fields": F, "full_scale": 1.0, "tolerance": 1e-5,
+            "against": "oracle/_ref (the compiled reference)" if use_ref else "oracle/ (C restatement)",
+            "measured": "in this run: the handle's first batch, before the warm-up",
+            "checker_seconds": round(time.perf_counter() - t0, 2)}
 
 
 def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
@@ -413,6 +471,16 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
             if k >= 0:
                 rs_ev[k][1].record()
 
+    # the handle's very first batch (zero history, field index 0): two channels of its IQ are kept on the host and
+    # compared with the CPU checker after the timed region (`iq_max_abs_error_vs_oracle`)
+    check_channels = sorted({0, C_ - 1})
+    first_iq = None
+    extras = rk.rank == 0 and not args.no_extras and rs is None
+    if extras and iq_bytes == 8 and up == 1:
+        step()
+        torch.cuda.synchronize()
+        per_ch = F * FIELD_SYMBOLS * 8
+        first_iq = {c: iq[c * per_ch:(c + 1) * per_ch].cpu().numpy().view("float32") for c in check_channels}
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -429,6 +497,56 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     sym_per_step_gpu = C_ * F * FIELD_SYMBOLS
     msym_s = sym_per_step_gpu * args.steps * rk.world / elapsed / 1e6
     stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, iq_bytes, msym_s, rk.world, up)
+
+    # ---- legs behind the headline loop (rank 0; the other ranks idle at the final barrier of run_gpu)
+    sustained = fp32_form = None
+    if extras:
+        if args.sustain_seconds > 0:
+            n = max(args.steps, int(args.sustain_seconds / (elapsed / args.steps)) + 1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            sustained = {"steps": n, "seconds": round(dt, 3), "ms_per_step": round(dt / n * 1e3, 4),
+                         "value": round(sym_per_step_gpu * n / dt / 1e6, 2), "unit": "Msym/s (this GPU)",
+                         "note": "back-to-back steps right after the headline loop, same handle and buffers"}
+        if fused and up == 1:
+            # the same shard at the reference's arithmetic: fp32 throughout (k_trellis_map + k_mix_fir_fft)
+            e32 = atsc_amd.Encoder(channels=C_, max_fields=F, device=rk.local_rank, timing=True)
+            e32.set_iq_format(fmt)
+            e32.set_fir_form(atsc_amd.FIR_FFT)
+            n32 = max(5, min(args.steps, 20))
+            for _ in range(3):
+                e32.encode_batch(ts.data_ptr(), F, None, iq.data_ptr(), stream)
+            torch.cuda.synchronize()
+            e32.timing_reserve(n32)
+            t1 = time.perf_counter()
+            for _ in range(n32):
+                e32.encode_batch(ts.data_ptr(), F, None, iq.data_ptr(), stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            st32 = {k: 0.0 for k in atsc_amd.STAGE_NAMES}
+            for b in range(n32):
+                tm = e32.batch_timings(b)
+                for k in st32:
+                    st32[k] += tm[k] / n32
+            fir32 = st32["mix_fir"] / 1e3
+            gbs32 = (1.0 + iq_bytes) * sym_per_step_gpu / fir32 / 1e9
+            fp32_form = {"fir_form": "fft (fp32 throughout: k_trellis_map writes u8 symbols, k_mix_fir_fft reads them)",
+                         "steps": n32, "ms_per_step": round(dt / n32 * 1e3, 4),
+                         "value": round(sym_per_step_gpu * n32 / dt / 1e6, 2), "unit": "Msym/s (this GPU)",
+                         "stage_ms": {k: round(v, 4) for k, v in st32.items()},
+                         "roofline": {"kernel": "k_mix_fir_fft", "bound": "hbm", "achieved": round(gbs32, 1), "peak": HBM_PEAK_GBS,
+                                      "unit": "GB/s", "frac": round(gbs32 / HBM_PEAK_GBS, 4),
+                                      "note": f"1 B u8 symbol in + {iq_bytes} B out per symbol; the step also pays k_trellis_map"}}
+            del e32
+    if first_iq is not None:
+        try:
+            roofline["iq_max_abs_error_vs_oracle"] = iq_error_in_run(ts, first_iq, F)
+        except Exception as e:  # the checker must never take the bench down
+            roofline["iq_max_abs_error_vs_oracle"] = {"error": repr(e)}
     resampler = None
     if rs is not None:
         ms = sum(a.elapsed_time(b) for a, b in rs_ev) / args.steps
@@ -446,9 +564,7 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         "metric": METRIC, "value": round(msym_s, 2), "unit": "Msym/s", "n_gpus": rk.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (oscillator recursion and accumulation in fp32; the mixer product and the FIR's multiplies run on two "
-                  "fp16 pieces of each fp32 operand, matrix cores; the low-order pieces are left out for the outermost taps: "
-                  "1.5e-6 of full scale measured, 7.1e-6 worst case by construction, tolerance 1e-5)" if fused else "f32"),
+        "dtype": FUSED_DTYPE if fused else "f32",
         "data": "synthetic",
         "config": {"workload": f"{C_} channels x {F} fields per GPU per step (BASELINE config 4 per-GPU shard), "
                                f"TS resident in HBM, {'symbol tap + ' if args.symbol_tap else ''}"
@@ -461,6 +577,11 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         "roofline": roofline,
         "roofline_other_stages": stages,
     }
+    if sustained:
+        res["sustained"] = sustained
+    if fp32_form:
+        res["fp32_form"] = fp32_form
+    res["kernel_sources_changed_since_profile"] = stages.get("_from_committed_profile", {}).get("kernel_sources_changed_since_profile")
     if up != 1:
         res["upsample"] = {"factor": up, "out_msamples_s": round(msym_s * up, 1),
                            "parity": "even samples: the reference's IQ bit for bit (pinned by the oracle); odd samples unpinned (no "
@@ -482,7 +603,11 @@ def bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     # The stream: every rank generates the same fields [0, W*F) from one seed (only a one-field halo is ever needed
     # from the neighbour, and it is part of the stream: no transfer).  Steps re-use these fields at later field
     # indices (the TS content does not matter for timing; field parity and oscillator phase follow the index).
-    ts_all = make_ts(torch, C_, W * F, 4242).view(C_, W * F, 312 * 188)
+    # With ONE rank the check would be vacuous (a span that starts at field 0 needs no halo, no seek and no carry), so the
+    # stream is then two spans long and this rank encodes both, the second on a handle of its own that starts mid-stream
+    # with the first span's parity as its carry: halo, seek and hand-off are all compared.
+    S = W if W > 1 else 2
+    ts_all = make_ts(torch, C_, S * F, 4242).view(C_, S * F, 312 * 188)
     my_ts = ts_all[:, rk.rank * F:(rk.rank + 1) * F].contiguous()
     halo = ts_all[:, rk.rank * F - 1].contiguous() if rk.rank else None
     any_halo = halo if halo is not None else ts_all[:, 0].contiguous()   # later steps: every rank starts mid-stream
@@ -493,33 +618,41 @@ def bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     # ---- parity of the first step against ONE handle encoding the whole stream (rank 0 holds the comparison)
     tse = TimeSplitEncoder(F, device=rk.local_rank, channels=C_, fir_form=form, iq_format=fmt)
     tse.prepare(rk.rank * F, halo)
-    tse.encode(my_ts, d_sym, d_iq, group)
+    par0 = tse.encode(my_ts, d_sym, d_iq, group)
     torch.cuda.synchronize()
     parity = {"checked": False}
-    check_fields = W * F
+    check_fields = S * F
     if check_fields * C_ * FIELD_SYMBOLS * (1 + sample_bytes) <= 64e9:
-        if rk.dist is not None:
+        if W > 1:
             syms = [torch.empty_like(d_sym) for _ in range(W)] if rk.rank == 0 else None
             iqs = [torch.empty_like(d_iq) for _ in range(W)] if rk.rank == 0 else None
             rk.dist.gather(d_sym, syms, dst=0)
             rk.dist.gather(d_iq, iqs, dst=0)
         else:
-            syms, iqs = [d_sym], [d_iq]
+            tse1 = TimeSplitEncoder(F, device=rk.local_rank, channels=C_, fir_form=form, iq_format=fmt)
+            tse1.prepare(F, ts_all[:, F - 1].contiguous())
+            sym1, iq1 = torch.empty_like(d_sym), torch.empty_like(d_iq)
+            tse1.encode(ts_all[:, F:2 * F].contiguous(), sym1, iq1, group, exchange=lambda par, grp: par0.clone())
+            torch.cuda.synchronize()
+            syms, iqs = [d_sym, sym1], [d_iq, iq1]
+            del tse1
         if rk.rank == 0:
-            whole = atsc_amd.Encoder(channels=C_, max_fields=W * F, device=rk.local_rank)
+            whole = atsc_amd.Encoder(channels=C_, max_fields=S * F, device=rk.local_rank)
             whole.set_iq_format(fmt)
             whole.set_fir_form(tse.enc.fir_form())
-            w_sym = torch.empty(C_ * W * n_span, dtype=torch.uint8, device="cuda")
-            w_iq = torch.empty(C_ * W * n_span * sample_bytes, dtype=torch.uint8, device="cuda")
-            whole.encode_batch(ts_all.data_ptr(), W * F, w_sym.data_ptr(), w_iq.data_ptr(),
+            w_sym = torch.empty(C_ * S * n_span, dtype=torch.uint8, device="cuda")
+            w_iq = torch.empty(C_ * S * n_span * sample_bytes, dtype=torch.uint8, device="cuda")
+            whole.encode_batch(ts_all.data_ptr(), S * F, w_sym.data_ptr(), w_iq.data_ptr(),
                                torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            w_sym = w_sym.view(C_, W, n_span)
-            w_iq = w_iq.view(C_, W, n_span * sample_bytes)
-            sym_bad = sum(int((syms[r].view(C_, n_span) != w_sym[:, r]).sum()) for r in range(W))
-            iq_bad = sum(int((iqs[r].view(C_, n_span * sample_bytes) != w_iq[:, r]).sum()) for r in range(W))
-            parity = {"checked": True, "fields": check_fields, "symbol_mismatches": sym_bad, "iq_byte_mismatches": iq_bad,
-                      "against": "one handle encoding the whole stream on rank 0 (atsc_hip_encode_batch)"}
+            w_sym = w_sym.view(C_, S, n_span)
+            w_iq = w_iq.view(C_, S, n_span * sample_bytes)
+            sym_bad = sum(int((syms[r].view(C_, n_span) != w_sym[:, r]).sum()) for r in range(S))
+            iq_bad = sum(int((iqs[r].view(C_, n_span * sample_bytes) != w_iq[:, r]).sum()) for r in range(S))
+            parity = {"checked": True, "fields": check_fields, "spans": S, "symbol_mismatches": sym_bad, "iq_byte_mismatches": iq_bad,
+                      "against": "one handle encoding the whole stream on rank 0 (atsc_hip_encode_batch)"
+                                 + ("" if W > 1 else "; one rank: both spans encoded here, the second from a one-field halo, a seek "
+                                                     "to its first field and the first span's parity as carry")}
             del whole, w_sym, w_iq, syms, iqs
             if sym_bad or iq_bad:
                 raise SystemExit(f"time-split output differs from the continuous encode: {parity}")
@@ -558,15 +691,18 @@ def bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     return {
         "metric": METRIC, "value": round(msym_s, 2), "unit": "Msym/s", "n_gpus": W, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if tse.enc.fir_form() == atsc_amd.FIR_FFT else FUSED_DTYPE, "data": "synthetic",
         "config": {"workload": f"BASELINE config 5: {C_} transport stream(s) time-split at field boundaries, {W} span(s) of "
                                f"{F} fields per step (one per GPU), trellis state handed over by a {16 * C_}-byte all-gather, "
                                f"interleaver history from a one-field TS halo; {args.iq_format} IQ to a device-resident sink",
                    "channels": C_, "fields_per_span": F, "parallelism": f"time-split x{W}, one all-gather per step"},
         "realtime_channels": round(msym_s / SYMBOL_RATE_MSPS, 1),
         "handoff_latency_us_median": round(handoff_us, 1),
-        "handoff_note": "host-timed: device sync, all-gather of the span parities (RCCL), XOR fold, device sync; max over ranks "
-                        "of each rank's median",
+        "handoff_note": ("host-timed: device sync, all-gather of the span parities over RCCL (device tensors), XOR fold, device "
+                         "sync; max over ranks of each rank's median" if rk.backend == "nccl" else
+                         "no collective ran (single process, no process group): the figure is two device syncs around a "
+                         "zero-fill, not a hand-off; run with --rccl (or under torchrun) for an RCCL-backed figure"),
         "parity": parity,
         "fir_form": {atsc_amd.FIR_FFT: "fft", atsc_amd.FIR_MFMA: "mfma", atsc_amd.FIR_FUSED: "fused"}[tse.enc.fir_form()],
     }
@@ -575,7 +711,7 @@ def bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.rccl) and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args, argv))
 
     # stdout carries exactly one JSON line: whatever libraries print there (RCCL's version banner, ...) goes to stderr

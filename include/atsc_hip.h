@@ -53,6 +53,10 @@ typedef struct atsc_hip_config {
 #define ATSC_HIP_FLAG_TAPS 2   /* also materialise the RS-coded byte stream of every batch (atsc_hip_stage_buffer
                                   ATSC_HIP_STAGE_RAND_RS); the path itself goes TS + parity -> interleaver directly */
 
+#define ATSC_HIP_FLAG_STRICT_FP32 4 /* the reference's arithmetic only (src/atsc/filter.h:16-69 is fp32 FMA): AUTO never picks a matrix-core
+                                  form, atsc_hip_set_fir_form(MFMA / FUSED) and atsc_hip_set_upsample(2) return ATSC_HIP_ERR_ARG.  The
+                                  IQ bits of such a handle do not depend on its channel count (see atsc_hip_get_fir_form) */
+
 /* Stage ids for atsc_hip_stage_buffer / atsc_hip_last_timings. */
 enum {
     ATSC_HIP_STAGE_RAND_RS = 0,   /* randomizer + RS(207,187)            -> coded bytes   */
@@ -87,6 +91,9 @@ void atsc_hip_destroy(atsc_hip_encoder* enc);
  * batches, the upload and kernels of batch k+1 overlap the download and callbacks of batch k (two internal slots
  * and streams) -- nothing stays in flight when the call returns.  A trailing partial field stays buffered (no flush
  * API, like the reference).
+ * Stream order: the call runs on streams of its own; it first waits (on the device) for whatever the last batch call or
+ * atsc_hip_seek on this handle queued on the caller's stream, and returns with its own streams drained, so batch and
+ * streaming calls on one handle may be mixed from one host thread without a synchronisation in between.
  * Errors: packets that were handed to the GPU before a failure are dropped from the buffer (they have advanced the
  * stream state and are not encoded twice); after any error return from a process / encode call the handle's stream
  * state (interleaver history, trellis state, oscillator) is undefined until atsc_hip_import_state re-seats it.  A
@@ -152,7 +159,11 @@ enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2, ATSC_
 int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);
 /* The form the handle's next batch runs (AUTO resolved: a function of the channel count and the setting only), or a
  * negative error code.  The forms differ in the last bits of the IQ, so the ranks of a time-split must
- * all run the same one for the spans to join bit-identically: atsc_amd/timesplit.py compares this value across ranks. */
+ * all run the same one for the spans to join bit-identically: atsc_amd/timesplit.py compares this value across ranks.
+ * REPRODUCIBILITY: under AUTO the IQ bits of a stream therefore depend on how many channels share its handle (a 12-channel
+ * handle runs FFT, a 13-channel one FUSED); every form is within the 1e-5 tolerance of the reference, none is bit-identical
+ * to another.  Callers that need the same bits whatever the grouping pin the form (atsc_hip_set_fir_form) or create the
+ * handle with ATSC_HIP_FLAG_STRICT_FP32. */
 int atsc_hip_get_fir_form(atsc_hip_encoder* enc);
 
 /* Interpolating form of the filter (the "upsampling FIR to the SDR rate"): factor 2 makes every d_iq / h_iq /
@@ -227,7 +238,11 @@ int atsc_hip_import_state(atsc_hip_encoder* enc, int channel, const atsc_hip_str
  * then atsc_hip_encode_begin / _finish with the carry of the earlier spans.  It does for all channels at once what an
  * atsc_hip_export_state / atsc_hip_import_state pair per channel did through the host.  No reference counterpart: the
  * reference cannot start mid-stream (atsc.cpp:34-40 zero state only).
- * Returns ATSC_HIP_ERR_STATE between atsc_hip_encode_begin and _finish. */
+ * Returns ATSC_HIP_ERR_STATE between atsc_hip_encode_begin and _finish.
+ * The oscillator walk is one dependent fp32 step per field: at most ATSC_HIP_MAX_SEEK_STEPS of them per call (counted from
+ * the handle's current index when the target lies ahead, from 0 otherwise), ATSC_HIP_ERR_TOO_LARGE beyond; the same bound
+ * applies to the field_index of atsc_hip_import_state.  The handle's host-side state moves only if every launch was accepted. */
+#define ATSC_HIP_MAX_SEEK_STEPS ((uint64_t)1 << 24)
 int atsc_hip_seek(atsc_hip_encoder* enc, uint64_t field_index, void* stream);
 
 /* Trellis parity of a span of fields encoded from zero trellis state: out36[0..11]=z2, [12..23]=z0_next,

@@ -49,7 +49,8 @@ with open(os.path.join(dst, "counters.csv"), "w", newline="") as fo:
 
 # HBM traffic per launch of the dominant kernel, corrected as MI355X_MICROARCH.md prescribes for gfx950:
 # FETCH_SIZE (KiB) counts 128-B read requests at 64 B -> x2 for wide coalesced reads; WRITE_SIZE (KiB) is exact.
-fir = next((k for k in ours if k.startswith("atsc_k::k_mix_fir_mm<0, true")), None) or \
+fir = next((k for k in ours if k.startswith("atsc_k::k_mix_fir_w")), None) or \
+      next((k for k in ours if k.startswith("atsc_k::k_mix_fir_mm<0, true")), None) or \
       next((k for k in ours if k.startswith("atsc_k::k_mix_fir")), None)
 if fir and "FETCH_SIZE" in mean[fir] and "WRITE_SIZE" in mean[fir]:
     fetch, write = mean[fir]["FETCH_SIZE"] * 1024 * 2, mean[fir]["WRITE_SIZE"] * 1024
@@ -102,5 +103,9 @@ if fir:
         for n in rows:
             if n in mean[fir]:
                 fo.write(f"| {n} | {round(mean[fir][n]):,} |\n".replace(",", " "))
+# what the passes were taken from: bench.py compares this with the tree it runs from (kernel_sources_changed_since_profile)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+open(os.path.join(dst, "kernel_sources.sha256"), "w").write(f"{bench.kernel_sources_hash()}  atsc_amd/csrc device sources ({', '.join(bench.KERNEL_SOURCES)}), commit {commit}\n")
 print(open(os.path.join(dst, "counters.csv")).read())
 print(open(os.path.join(dst, "utilisation.json")).read())
