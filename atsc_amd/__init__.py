@@ -71,7 +71,7 @@ class IngestStats(C.Structure):
 FIELD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint)
 CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
-FIR_AUTO, FIR_FFT, FIR_MFMA, FIR_FUSED = 0, 1, 2, 3
+FIR_AUTO, FIR_FFT, FIR_MFMA, FIR_FUSED, FIR_WIDE = 0, 1, 2, 3, 4
 ERR_ARG, ERR_NO_DEVICE, ERR_TOO_LARGE, ERR_STATE = -1, -2, -3, -4   # include/atsc_hip.h
 
 _lib = None

@@ -181,6 +181,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     e->dtab.prbs_rows = tb + off_prr;
     TRY_OR_FREE(upload_fft_tables(e->tab.taps));
     TRY_OR_FREE(upload_mm_tables(e->tab.taps, e->tab.taps_half));
+    TRY_OR_FREE(upload_w_tables(e->tab.taps));
 
     // per-channel working buffers
     e->buf.max_fields = cfg->max_fields;
@@ -290,6 +291,15 @@ bool matrix_forms_fit(const atsc_hip_encoder* e, int iq_format, int upsample) {
     return 16 * row_bytes <= 0xffffffffull;
 }
 
+// The wide kernel (fir_w.hip) works on groups of 64 channels, writes complex64 at one sample per symbol, and addresses eight
+// channel rows of the batch's IQ (and all 64 rows of the optional symbol tap) through 32-bit offsets.
+bool wide_form_fits(const atsc_hip_encoder* e, int iq_format, int upsample) {
+    if (iq_format != ATSC_HIP_IQ_CF32 || upsample != 1) return false;
+    if (e->cfg.channels % kWideGroup) return false;   // whole groups only: its stores carry no range check
+    const uint64_t row_bytes = (uint64_t)e->cfg.max_fields * kFieldSyms * sizeof(float2);
+    return 8 * row_bytes <= 0xffffffffull && (uint64_t)kWideGroup * e->cfg.max_fields * kFieldSyms <= 0xffffffffull;
+}
+
 int resolve_fir_form(const atsc_hip_encoder* e) {
     if (e->fir_form != ATSC_HIP_FIR_AUTO) return e->fir_form;
     if (e->cfg.flags & ATSC_HIP_FLAG_STRICT_FP32) return ATSC_HIP_FIR_FFT;   // (set_upsample(2) is refused on such a handle)
@@ -297,6 +307,8 @@ int resolve_fir_form(const atsc_hip_encoder* e) {
     if (!matrix_forms_fit(e, e->iq_format, 1)) return ATSC_HIP_FIR_FFT;
     // The fused kernel works on groups of kFusedGroup channels and costs the same for a partly filled group, the FFT
     // form costs per channel: fused when at least 80 % of the matrix columns carry a channel.
+    // (the wide form is never AUTO's choice: at the bench shard it is 7 % slower than FUSED; it is the form to ask for when
+    // the tighter error bound matters)
     const int groups = (e->cfg.channels + kFusedGroup - 1) / kFusedGroup;
     if (5 * e->cfg.channels >= 4 * kFusedGroup * groups) return ATSC_HIP_FIR_FUSED;
     return ATSC_HIP_FIR_FFT;
@@ -312,7 +324,7 @@ int run_mix_fir(atsc_hip_encoder* e, const uint8_t* d_sym, size_t sym_stride, vo
         // (the fused form does not come through here, except for atsc_hip_mix_fir on a 2x handle: caller-supplied symbols
         // then take the matrix-core kernel's unfused instance, the only other one that interpolates)
         const bool mfma = form == ATSC_HIP_FIR_MFMA || e->upsample != 1;
-        launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields, mfma);
+        launch_osc_table(s, oin, oout, e->d_osc_tab, e->scale, fields, mfma ? kOscPlanes4096 : kOscComplex);
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
         if (mfma)
             launch_mix_fir_mfma(s, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms * e->upsample,
@@ -370,7 +382,9 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
     e->last_stream = s;
     const size_t sym_stride = (size_t)fields * kFieldSyms;
     int rc;
-    const bool fused = d_iq && resolve_fir_form(e) == ATSC_HIP_FIR_FUSED;
+    const int form = resolve_fir_form(e);
+    const bool wide = d_iq && form == ATSC_HIP_FIR_WIDE;
+    const bool fused = d_iq && (form == ATSC_HIP_FIR_FUSED || wide);
     if (!fused && !d_sym) {
         rc = ensure_sym_buffer(e);
         if (rc) return rc;
@@ -382,9 +396,14 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
         mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);
         launch_trellis_scan(s, e->buf, static_cast<const uint4*>(d_carry_xor), e->cfg.channels, fields);
         mark(e, s, ATSC_HIP_STAGE_OSC);
-        launch_osc_table(s, e->d_osc[e->osc_cur], e->d_osc[e->osc_cur ^ 1], e->d_osc_tab, e->scale, fields, true);
+        launch_osc_table(s, e->d_osc[e->osc_cur], e->d_osc[e->osc_cur ^ 1], e->d_osc_tab, e->scale, fields,
+                         wide ? kOscPlanes16 : kOscPlanes4096);
         e->osc_cur ^= 1;
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
+        if (wide)
+            launch_mix_fir_wide(s, e->dtab, e->buf, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms,
+                                reinterpret_cast<const float*>(e->d_osc_tab), e->cfg.channels, fields, e->field_index);
+        else
         launch_mix_fir_fused(s, e->dtab, e->buf, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms * e->upsample,
                              reinterpret_cast<const float*>(e->d_osc_tab), e->cfg.channels, fields, e->field_index,
                              e->iq_format, e->upsample);
@@ -479,8 +498,14 @@ extern "C" size_t atsc_hip_iq_sample_bytes(int format) {
 }
 
 extern "C" int atsc_hip_set_fir_form(atsc_hip_encoder* e, int form) {
-    if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_FUSED) return ATSC_HIP_ERR_ARG;
+    if (!e || form < ATSC_HIP_FIR_AUTO || form > ATSC_HIP_FIR_WIDE) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if (form == ATSC_HIP_FIR_WIDE) {
+        if (e->cfg.flags & ATSC_HIP_FLAG_STRICT_FP32) return ATSC_HIP_ERR_ARG;
+        // complex64, one sample per symbol, whole groups of 64 channels only
+        if (e->iq_format != ATSC_HIP_IQ_CF32 || e->upsample != 1 || e->cfg.channels % kWideGroup) return ATSC_HIP_ERR_ARG;
+        if (!wide_form_fits(e, e->iq_format, e->upsample)) return ATSC_HIP_ERR_TOO_LARGE;
+    }
     if ((form == ATSC_HIP_FIR_MFMA || form == ATSC_HIP_FIR_FUSED) && (e->cfg.flags & ATSC_HIP_FLAG_STRICT_FP32)) return ATSC_HIP_ERR_ARG;
     if ((form == ATSC_HIP_FIR_MFMA || form == ATSC_HIP_FIR_FUSED) && !matrix_forms_fit(e, e->iq_format, e->upsample)) return ATSC_HIP_ERR_TOO_LARGE;
     if (form == ATSC_HIP_FIR_FFT && e->upsample != 1) return ATSC_HIP_ERR_ARG;   // the FFT form does not interpolate
@@ -496,6 +521,7 @@ extern "C" int atsc_hip_get_fir_form(atsc_hip_encoder* e) {
 extern "C" int atsc_hip_set_iq_format(atsc_hip_encoder* e, int format) {
     if (!e || !atsc_hip_iq_sample_bytes(format)) return ATSC_HIP_ERR_ARG;
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
+    if (e->fir_form == ATSC_HIP_FIR_WIDE && format != ATSC_HIP_IQ_CF32) return ATSC_HIP_ERR_ARG;
     if ((e->fir_form == ATSC_HIP_FIR_MFMA || e->fir_form == ATSC_HIP_FIR_FUSED || e->upsample != 1) && !matrix_forms_fit(e, format, e->upsample))
         return ATSC_HIP_ERR_TOO_LARGE;
     e->iq_format = format;
@@ -507,6 +533,7 @@ extern "C" int atsc_hip_set_upsample(atsc_hip_encoder* e, int factor) {
     if (e->pending_fields) return ATSC_HIP_ERR_STATE;
     if (factor == e->upsample) return ATSC_HIP_OK;
     if (factor == 2) {
+        if (e->fir_form == ATSC_HIP_FIR_WIDE) return ATSC_HIP_ERR_ARG;
         if (e->fir_form == ATSC_HIP_FIR_FFT || (e->cfg.flags & ATSC_HIP_FLAG_STRICT_FP32)) return ATSC_HIP_ERR_ARG;
         if (!matrix_forms_fit(e, e->iq_format, 2)) return ATSC_HIP_ERR_TOO_LARGE;
     }

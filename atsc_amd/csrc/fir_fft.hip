@@ -346,8 +346,9 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
 
 // Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41).
 // planes != 0: the layout of the matrix-core forms (fir_fused.hip): [f][re plane | im plane] of kPaddedSyms dwords, where
-// the dwords 2m, 2m+1 of a plane hold the positions 2m and 2m+1 as fp16 pieces of T * 4096 (kZScale: fp16's normal range):
-// {Th(2m), Th(2m+1)}, {Tl(2m), Tl(2m+1)} with Th = fl16(T * 4096), Tl = fl16(T * 4096 - Th).
+// the dwords 2m, 2m+1 of a plane hold the positions 2m and 2m+1 as fp16 pieces of T * S (fp16's normal range; S = 4096 for
+// fir_fused.hip, kOscPlanes4096, and 16 for fir_w.hip, kOscPlanes16):
+// {Th(2m), Th(2m+1)}, {Tl(2m), Tl(2m+1)} with Th = fl16(T * S), Tl = fl16(T * S - Th).
 __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in, float2* __restrict__ tab,
                                                    float2* __restrict__ out, float2 sc, int fields, int planes) {
     // a thread owns two neighbouring table entries: the plane form packs their fp16 pieces into whole dwords (dword 2m of a
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in
     const float4 t01 = reinterpret_cast<const float4*>(in)[m];
     float2 t[2] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w)};
     float* pl = reinterpret_cast<float*>(tab);
+    const float pscale = planes == kOscPlanes16 ? 16.0f : 4096.0f;
     for (int f = 0; f < fields; ++f) {
         if (planes) {
 #pragma unroll
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in
                 _Float16 hi[2], lo[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float v = (c ? t[j].y : t[j].x) * 4096.0f;
+                    const float v = (c ? t[j].y : t[j].x) * pscale;
                     hi[j] = (_Float16)v;
                     lo[j] = (_Float16)(v - (float)hi[j]);
                 }
@@ -418,9 +420,9 @@ hipError_t upload_fft_tables(const float* taps112) {
 }
 
 void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields,
-                      bool planes) {
+                      int planes) {
     hipLaunchKernelGGL(k_osc_table, dim3((kPaddedSyms / 2 + 255) / 256), dim3(256), 0, s, osc_in, osc_tab, osc_out, scale,
-                       fields, planes ? 1 : 0);
+                       fields, planes);
 }
 
 template <int FMT>

@@ -69,8 +69,11 @@ void launch_osc_advance(hipStream_t s, const float2* osc_in, float2* osc_out, fl
 // Mixer + FIR (fir_fft.hip).  osc_tab: (fields x 261248 + kOscTabSlack) complex64 scratch.
 // launch_osc_table fills osc_tab[f] = T_(f0+f) for the batch from the state osc_in and leaves the state after the
 // batch in osc_out (offset.h:35-41); launch_mix_fir_fft then produces the IQ of every (channel, field).
+// planes: 0 = complex64 entries (FFT form); kOscPlanes4096 / kOscPlanes16 = the fp16-piece planes of the matrix-core forms, the
+// entries scaled by 2^12 (fir_fused.hip) or 2^4 (fir_w.hip)
+constexpr int kOscComplex = 0, kOscPlanes4096 = 1, kOscPlanes16 = 2;
 void launch_osc_table(hipStream_t s, const float2* osc_in, float2* osc_out, float2* osc_tab, float2 scale, int fields,
-                      bool planes);
+                      int planes);
 // iq_format: kIqCf32 (complex64, the reference's payload) / kIqCs16 / kIqCs8 (SDR sink formats); iq_stride in samples.
 void launch_mix_fir_fft(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
                         float2* osc_tab, int channels, int fields, int iq_format);
@@ -86,6 +89,12 @@ hipError_t upload_mm_tables(const float* taps112, const float* taps_half112);   
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                           size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
                           int iq_format, int upsample);
+// The fused kernel with the oscillator folded into the tap operand (fir_w.hip): 64 channels per wave task, complex64 output,
+// one sample per symbol.  osc_planes: launch_osc_table(..., kOscPlanes16).
+void launch_mix_fir_wide(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
+                         size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base);
+hipError_t upload_w_tables(const float* taps112);
+constexpr int kWideGroup = 64;    // channels per wave task of fir_w.hip
 constexpr int kFusedGroup = 16;   // channels per wave task of the fused kernel: a partly filled group costs as much as a full one
 
 }  // namespace atsc_k

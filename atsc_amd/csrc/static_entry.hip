@@ -78,7 +78,7 @@ int setup_device_once(DeviceSetup& d) {
     // module warm-up: one field of one channel, symbols read from the (initialised) T_0 bytes, IQ written into the slot of
     // the batch table's third field; every result is overwritten by the first real call
     launch_osc_advance(nullptr, p + kOffT0, p + kOffStateA, d.scale, 1);
-    launch_osc_table(nullptr, p + kOffStateA, p + kOffStateB, p + kOffTab, d.scale, 1, false);
+    launch_osc_table(nullptr, p + kOffStateA, p + kOffStateB, p + kOffTab, d.scale, 1, kOscComplex);
     for (int fmt : {ATSC_HIP_IQ_CF32, ATSC_HIP_IQ_CS16, ATSC_HIP_IQ_CS8})
         launch_mix_fir_fft(nullptr, reinterpret_cast<const uint8_t*>(p + kOffT0), kFieldSyms, p + kOffTab + 2 * (size_t)kPaddedSyms,
                            kFieldSyms, p + kOffTab, 1, 1, fmt);
@@ -129,7 +129,7 @@ extern "C" int atsc_hip_mix_fir_static(int device, const uint8_t* d_sym, int cha
         launch_osc_advance(s, t0, state_in, d.scale, (unsigned)field_index);
         osc_in = state_in;
     }
-    launch_osc_table(s, osc_in, state_out, tab, d.scale, fields, false);
+    launch_osc_table(s, osc_in, state_out, tab, d.scale, fields, kOscComplex);
     launch_mix_fir_fft(s, d_sym, (size_t)fields * kFieldSyms, d_iq, (size_t)fields * kFieldSyms, tab, channels, fields,
                        iq_format);
     return static_cast<int>(hipGetLastError());

@@ -45,6 +45,9 @@ FIELD_SYMBOLS = 313 * 832
 FUSED_DTYPE = ("f32 (oscillator recursion and accumulation in fp32; the mixer product and the FIR's multiplies run on two "
                "fp16 pieces of each fp32 operand, matrix cores; the low-order pieces are left out for the outermost taps: "
                "1.5e-6 of full scale measured, 7.1e-6 worst case by construction, tolerance 1e-5)")
+WIDE_DTYPE = ("f32 (oscillator recursion and accumulation in fp32; the tap x oscillator operand is formed per tile in two fp16 pieces, "
+              "the levels are exact in one, matrix cores; the low-order piece is left out for the two outermost K-steps: 1.2e-6 of "
+              "full scale measured, 3.7e-6 worst case by construction, tolerance 1e-5)")
 METRIC = "real-time ATSC channels per GPU (Msym/s; 10.76=1 ch) at 1/2/4/8 MI355X"
 PROFILE_ROUND = "r03"
 PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
@@ -148,7 +151,7 @@ def parse_args(argv=None):
     ap.add_argument("--iq-format", choices=("cf32", "cs16", "cs8"), default="cf32",
                     help="IQ sample format of the device sink; cf32 is the reference's payload and the headline "
                          "configuration, cs16/cs8 are the SDR sink formats (SURVEY 8f-3)")
-    ap.add_argument("--fir-form", choices=("auto", "fft", "mfma", "fused"), default="auto",
+    ap.add_argument("--fir-form", choices=("auto", "fft", "mfma", "fused", "wide"), default="auto",
                     help="A/B runs: which kernel computes the mixer + FIR (atsc_hip_set_fir_form)")
     ap.add_argument("--resample", default=None, metavar="L/M",
                     help="SURVEY 8f-1: follow the encoder with the SDR-rate polyphase resampler (include/atsc_hip_resample.h) "
@@ -325,7 +328,7 @@ def run_gpu(args, json_fd):
 
     fmt = {"cf32": atsc_amd.IQ_CF32, "cs16": atsc_amd.IQ_CS16, "cs8": atsc_amd.IQ_CS8}[args.iq_format]
     form = {"auto": atsc_amd.FIR_AUTO, "fft": atsc_amd.FIR_FFT, "mfma": atsc_amd.FIR_MFMA,
-            "fused": atsc_amd.FIR_FUSED}[args.fir_form]
+            "fused": atsc_amd.FIR_FUSED, "wide": atsc_amd.FIR_WIDE}[args.fir_form]
     sample_bytes = {"cf32": 8, "cs16": 4, "cs8": 2}[args.iq_format]
     if args.mode == "timesplit":
         res = bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes)
@@ -342,7 +345,7 @@ def run_gpu(args, json_fd):
     rk.finish()
 
 
-def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world, up=1):
+def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world, up=1, wide=False):
     """Per-stage kernel time from the HIP events of the timed region (this rank's GPU) and the roofline objects."""
     stage_ms = {k: 0.0 for k in atsc_amd.STAGE_NAMES}
     for b in range(args.steps):
@@ -385,7 +388,10 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world,
                        "note": "PMC passes of scripts/profile_gpu.sh (fetch, write) on the named commit, summarised by scripts/summarize_profile.py; not re-measured in this run"}
     stages["_from_committed_profile"] = replayed
     roofline = {
-        "kernel": ("k_mix_fir_mm<cf32, fused> (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes, "
+        "kernel": ("k_mix_fir_w (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes; FIR as Y = W.X on the "
+                   "matrix cores with W = taps x oscillator formed per tile in two fp16 pieces and shared by 64 channels, levels exact "
+                   "in one fp16 piece)" if wide else
+                   "k_mix_fir_mm<cf32, fused> (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes, "
                    "pilot + offset mixer first, then the 112-tap RRC FIR as Y = A.Z with a constant Toeplitz tap operand on the "
                    "matrix cores, fp16 hi/lo split of both operands)" if fused else
                    "k_mix_fir_fft (pilot/offset mixer + 112-tap RRC FIR, overlap-save 1024-point FFT form)"),
@@ -438,7 +444,8 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         if args.resample:
             raise SystemExit("--upsample and --resample are alternatives")
         enc.set_upsample(up)
-    fused = enc.fir_form() == atsc_amd.FIR_FUSED
+    wide = enc.fir_form() == atsc_amd.FIR_WIDE
+    fused = enc.fir_form() == atsc_amd.FIR_FUSED or wide
     ts = make_ts(torch, C_, F, 1234 + rk.rank)     # seeded per rank: every global channel its own stream
     sym = torch.empty(C_ * F * FIELD_SYMBOLS, dtype=torch.uint8, device="cuda") if args.symbol_tap else None
     stream = torch.cuda.current_stream().cuda_stream
@@ -496,7 +503,7 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
 
     sym_per_step_gpu = C_ * F * FIELD_SYMBOLS
     msym_s = sym_per_step_gpu * args.steps * rk.world / elapsed / 1e6
-    stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, iq_bytes, msym_s, rk.world, up)
+    stage_ms, roofline, stages = stage_report(args, atsc_amd, enc, C_, F, fused, iq_bytes, msym_s, rk.world, up, wide)
 
     # ---- legs behind the headline loop (rank 0; the other ranks idle at the final barrier of run_gpu)
     sustained = fp32_form = None
@@ -564,7 +571,7 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         "metric": METRIC, "value": round(msym_s, 2), "unit": "Msym/s", "n_gpus": rk.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": FUSED_DTYPE if fused else "f32",
+        "dtype": (WIDE_DTYPE if wide else FUSED_DTYPE) if fused else "f32",
         "data": "synthetic",
         "config": {"workload": f"{C_} channels x {F} fields per GPU per step (BASELINE config 4 per-GPU shard), "
                                f"TS resident in HBM, {'symbol tap + ' if args.symbol_tap else ''}"
@@ -704,7 +711,8 @@ def bench_timesplit(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
                          "no collective ran (single process, no process group): the figure is two device syncs around a "
                          "zero-fill, not a hand-off; run with --rccl (or under torchrun) for an RCCL-backed figure"),
         "parity": parity,
-        "fir_form": {atsc_amd.FIR_FFT: "fft", atsc_amd.FIR_MFMA: "mfma", atsc_amd.FIR_FUSED: "fused"}[tse.enc.fir_form()],
+        "fir_form": {atsc_amd.FIR_FFT: "fft", atsc_amd.FIR_MFMA: "mfma", atsc_amd.FIR_FUSED: "fused",
+                     atsc_amd.FIR_WIDE: "wide"}[tse.enc.fir_form()],
     }
 
 

@@ -148,14 +148,20 @@ size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown form
  *         regenerated from the interleaved bytes inside the kernel and never pass through HBM.  Only in
  *         atsc_hip_encode_batch / _finish with d_iq != NULL; d_sym is then an optional tap (NULL: no symbols are
  *         written anywhere and atsc_hip_stage_buffer(TRELLIS_MAP) returns ATSC_HIP_ERR_STATE)
- *   AUTO: FUSED when the handle's channels fill at least 80 % of whole groups of 16 (13..16, 26..32, 39..48, 52..),
+ *   WIDE: FUSED with the oscillator folded into the TAP operand instead of the sample operand (fir_w.hip): the levels are
+ *         exact in one fp16 piece, so a third fewer matrix products, shared by 64 channels per wave; complex64 at one sample
+ *         per symbol and a channel count that is a multiple of 64 only (ATSC_HIP_ERR_ARG otherwise); 3.7e-6 worst case by
+ *         construction, 1.2e-6 measured -- the tightest of the matrix-core forms -- at 7 % more time than FUSED on 64 channels
+ *         x 64 fields.  Never AUTO's choice: ask for it when the margin matters.
+ *   AUTO: FUSED when the handle's
+ *         channels fill at least 80 % of whole groups of 16 (13..16, 26..32, 39..48, 52..),
  *         FFT otherwise (default)
  * MFMA and FUSED address 16 channel rows of a batch's IQ through one 32-bit-offset buffer descriptor: they need
  * 16 * max_fields * 260416 * atsc_hip_iq_sample_bytes(format) < 4 GiB (max_fields <= 128 for CF32, 257 for CS16, 515
  * for CS8).  On a larger handle AUTO resolves to FFT, and asking for MFMA / FUSED (or switching such a handle to a wider
  * sample format) returns ATSC_HIP_ERR_TOO_LARGE.
  * No reference counterpart (the reference has one scalar/AVX form, filter.h:16-69). */
-enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2, ATSC_HIP_FIR_FUSED = 3 };
+enum { ATSC_HIP_FIR_AUTO = 0, ATSC_HIP_FIR_FFT = 1, ATSC_HIP_FIR_MFMA = 2, ATSC_HIP_FIR_FUSED = 3, ATSC_HIP_FIR_WIDE = 4 };
 int atsc_hip_set_fir_form(atsc_hip_encoder* enc, int form);
 /* The form the handle's next batch runs (AUTO resolved: a function of the channel count and the setting only), or a
  * negative error code.  The forms differ in the last bits of the IQ, so the ranks of a time-split must

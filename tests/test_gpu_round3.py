@@ -134,3 +134,58 @@ def test_streaming_call_is_ordered_behind_a_batch_on_another_stream(torch_cuda):
     assert np.abs(got[0] - want[2]).max() <= IQ_TOL
     first = torch.view_as_real(d_iq).cpu().numpy().reshape(2, -1)
     assert np.abs(first - want[:2]).max() <= IQ_TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the wide form (fir_w.hip): oscillator folded into the tap operand, 64 channels per wave
+
+
+@pytest.mark.parametrize("C_,nf", [(64, 3), (128, 1)])
+def test_wide_form_symbols_and_iq(torch_cuda, C_, nf):
+    """ATSC_HIP_FIR_WIDE regenerates the symbols inside the FIR kernel like FUSED (lane = channel).  Its symbol tap must
+    equal k_trellis_map's output bit for bit on every channel, its IQ must agree with the fp32 (FFT) form within a few
+    1e-6 on every channel and field, the IQ must not depend on whether the tap is taken, and nothing may be written past
+    the buffers; two consecutive batches exercise the carried state.  The first, a middle and the last channel are checked
+    against the oracle.  Handles whose channel count is not a multiple of 64 never run it."""
+    part = atsc_amd.Encoder(channels=52, max_fields=1)
+    assert part.fir_form() == atsc_amd.FIR_FUSED and _code(part.set_fir_form, atsc_amd.FIR_WIDE) == atsc_amd.ERR_ARG
+    assert atsc_amd.Encoder(channels=C_, max_fields=1).fir_form() == atsc_amd.FIR_FUSED   # AUTO never picks the wide form
+    from oracle_lib import ts_mix
+    torch = torch_cuda
+    per = [ts_mix(900 + c, 2 * nf) for c in range(C_)]
+    st = torch.cuda.current_stream().cuda_stream
+    n = C_ * nf * FIELD_SYMBOLS
+    outs = {}
+    for name, form, tap in (("fft", atsc_amd.FIR_FFT, True), ("wide", atsc_amd.FIR_WIDE, True), ("wide_notap", atsc_amd.FIR_WIDE, False)):
+        enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+        enc.set_fir_form(form)
+        if name != "fft":
+            assert enc.fir_form() == atsc_amd.FIR_WIDE
+        res = []
+        for b in range(2):
+            ts = np.concatenate([p[b * nf * FIELD_TS_BYTES:(b + 1) * nf * FIELD_TS_BYTES] for p in per])
+            d_ts = torch.from_numpy(ts).cuda()
+            d_sym = torch.full((n + 4096,), 0xEE, dtype=torch.uint8, device="cuda")
+            d_iq = torch.full((2 * n + 4096,), float("nan"), dtype=torch.float32, device="cuda")
+            enc.encode_batch(d_ts.data_ptr(), nf, d_sym.data_ptr() if tap else None, d_iq.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert bool((d_sym[n:] == 0xEE).all()) and bool(torch.isnan(d_iq[2 * n:]).all()), "wrote past the buffers"
+            res.append((d_sym[:n].view(C_, nf, -1), d_iq[:2 * n].view(C_, nf, -1)))
+        outs[name] = res
+    worst = 0.0
+    for b in range(2):
+        s_ref, q_ref = outs["fft"][b]
+        s_w, q_w = outs["wide"][b]
+        bad = (s_ref != s_w).nonzero()
+        assert bad.numel() == 0, f"batch {b}: {bad.shape[0]} symbol mismatches, first (ch, field, pos) {bad[:5].tolist()}"
+        assert not bool(torch.isnan(q_w).any()), f"batch {b}: IQ samples never written"
+        assert torch.equal(q_w.view(torch.int32), outs["wide_notap"][b][1].view(torch.int32)), "the symbol tap changes the IQ"
+        worst = max(worst, float((q_w - q_ref).abs().max()))
+    print(f"wide form vs fp32 form, {C_} ch x {nf} fields: max |dIQ| = {worst:.3e}")
+    assert worst <= 4e-6
+    for c in (0, C_ // 2 + 1, C_ - 1):
+        want = Oracle().process_fields(per[c], 2 * nf, want=("sym", "iq"))
+        got_sym = np.concatenate([outs["wide"][b][0][c].reshape(-1).cpu().numpy() for b in range(2)])
+        got_iq = np.concatenate([outs["wide"][b][1][c].reshape(-1).cpu().numpy() for b in range(2)])
+        assert np.array_equal(got_sym, want["sym"])
+        assert np.abs(got_iq - want["iq"]).max() <= IQ_TOL
