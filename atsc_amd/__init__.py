@@ -297,7 +297,8 @@ def get_table(which, handle=None):
     """Constant tables as the library builds them (no GPU needed when handle is None)."""
     import numpy as np
     shapes = {0: (112, np.float32), 1: (PADDED_SYMBOLS * 2, np.float32), 2: (2, np.float32),
-              3: (187 * 312, np.uint8), 4: (820, np.uint8), 5: (820, np.uint8), 6: (21, np.uint8), 7: (112, np.float32)}
+              3: (187 * 312, np.uint8), 4: (820, np.uint8), 5: (820, np.uint8), 6: (21, np.uint8), 7: (112, np.float32),
+              8: (2 * 2 * 9 * 64 * 8, np.uint16), 9: (2 * 8 * 64 * 8, np.uint16)}
     n, dt = shapes[which]
     out = np.zeros(n, dt)
     check(load_library().atsc_hip_get_table(handle, which, out.ctypes.data, out.nbytes))

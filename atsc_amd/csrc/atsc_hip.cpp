@@ -847,6 +847,23 @@ extern "C" int atsc_hip_get_table(atsc_hip_encoder* e, int which, void* h_out, s
         case 5: src = t->fsync[1].data(); n = 820; break;
         case 6: src = t->rs_gen; n = 21; break;
         case 7: src = t->taps_half; n = sizeof(float) * kTaps; break;
+        case 8:
+        case 9: {
+            // the matrix-core forms' tap operands as fp16 bit patterns: with a handle, read back from its device (what the
+            // kernels use); without, built on the host by the function whose output create() uploads
+            n = sizeof(uint16_t) * (which == 8 ? kMmOperandHalves : kWOperandHalves);
+            if (bytes < n) return ATSC_HIP_ERR_ARG;
+            if (e) {
+                HIP_TRY(hipSetDevice(e->cfg.device));
+                HIP_TRY(which == 8 ? download_mm_tables(static_cast<uint16_t*>(h_out)) : download_w_tables(static_cast<uint16_t*>(h_out)));
+                return ATSC_HIP_OK;
+            }
+            std::vector<uint16_t> op;
+            if (which == 8) build_mm_operand(t->taps, t->taps_half, op);
+            else build_w_operand(t->taps, op);
+            std::memcpy(h_out, op.data(), n);
+            return ATSC_HIP_OK;
+        }
         default: return ATSC_HIP_ERR_ARG;
     }
     if (bytes < n) return ATSC_HIP_ERR_ARG;

@@ -672,8 +672,8 @@ __global__ __launch_bounds__(64 * kWaves, UP == 1 ? 2 : 1) void k_mix_fir_mm(con
     }
 }
 
-hipError_t upload_mm_tables(const float* taps112, const float* taps_half112) {
-    std::vector<uint16_t> h(2 * 2 * kKSteps * 64 * 8);
+void build_mm_operand(const float* taps112, const float* taps_half112, std::vector<uint16_t>& h) {
+    h.assign(kMmOperandHalves, 0);
     for (int ph = 0; ph < 2; ++ph)
         for (int ks = 0; ks < kKSteps; ++ks)
             for (int lane = 0; lane < 64; ++lane)
@@ -688,7 +688,17 @@ hipError_t upload_mm_tables(const float* taps112, const float* taps_half112) {
                     h[((size_t)((2 * ph) * kKSteps + ks) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, hi);
                     h[((size_t)((2 * ph + 1) * kKSteps + ks) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, lo);
                 }
+}
+
+hipError_t upload_mm_tables(const float* taps112, const float* taps_half112) {
+    std::vector<uint16_t> h;
+    build_mm_operand(taps112, taps_half112, h);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_a_tab), h.data(), sizeof(uint16_t) * h.size());
+}
+
+// what the kernels of the current device actually read (tests: the error budget is computed from these bits)
+hipError_t download_mm_tables(uint16_t* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a_tab), sizeof(uint16_t) * kMmOperandHalves);
 }
 
 namespace {

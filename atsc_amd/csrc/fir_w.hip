@@ -538,8 +538,8 @@ __global__ __launch_bounds__(64 * kWWaves, 2) void k_mix_fir_w(const WArgs a) {
 }
 
 
-hipError_t upload_w_tables(const float* taps112) {
-    std::vector<uint16_t> hst(2 * kWK * 64 * 8);
+void build_w_operand(const float* taps112, std::vector<uint16_t>& hst) {
+    hst.assign(kWOperandHalves, 0);
     for (int ks = 0; ks < kWK; ++ks)
         for (int lane = 0; lane < 64; ++lane)
             for (int j = 0; j < 8; ++j) {
@@ -551,7 +551,16 @@ hipError_t upload_w_tables(const float* taps112) {
                 hst[((size_t)ks * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, hi);
                 hst[((size_t)(kWK + ks) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, lo);
             }
+}
+
+hipError_t upload_w_tables(const float* taps112) {
+    std::vector<uint16_t> hst;
+    build_w_operand(taps112, hst);
     return hipMemcpyToSymbol(HIP_SYMBOL(g_w_tab), hst.data(), sizeof(uint16_t) * hst.size());
+}
+
+hipError_t download_w_tables(uint16_t* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_w_tab), sizeof(uint16_t) * kWOperandHalves);
 }
 
 void launch_mix_fir_wide(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,

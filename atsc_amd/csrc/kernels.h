@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 namespace atsc_k {
 
@@ -84,6 +85,12 @@ hipError_t upload_fft_tables(const float* taps112);
 void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride, void* d_iq, size_t iq_stride,
                          const float* osc_planes, int channels, int fields, int iq_format, int upsample);
 hipError_t upload_mm_tables(const float* taps112, const float* taps_half112);   // fir_fused.hip: the Toeplitz tap operands
+// The operand itself, as fp16 bit patterns in the kernel's register order [phase][hi, lo][K-step 0..8][lane 0..63][8]: lane
+// (p = lane & 31, h = lane >> 5) of K-step ks holds taps[16 ks + 8 h + j - p] x 2^16.  build_: on the host (no GPU);
+// download_: read back from the current device's copy.
+constexpr size_t kMmOperandHalves = 2 * 2 * 9 * 64 * 8;
+void build_mm_operand(const float* taps112, const float* taps_half112, std::vector<uint16_t>& out);
+hipError_t download_mm_tables(uint16_t* out);
 // The same with the trellis / map / sync stage fused in: symbols are regenerated from b.il + b.cin inside the kernel and
 // never pass through HBM; d_sym (the symbol tap) may be NULL.  Replaces launch_trellis_map + launch_mix_fir_mfma.
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
@@ -94,6 +101,10 @@ void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b
 void launch_mix_fir_wide(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                          size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base);
 hipError_t upload_w_tables(const float* taps112);
+// fir_w.hip's tap operand [hi, lo][K-step 0..7][lane][8]: lane (p = (lane & 31) >> 1, h = lane >> 5) holds taps[16 ks + 8 h + j - p] x 2^8
+constexpr size_t kWOperandHalves = 2 * 8 * 64 * 8;
+void build_w_operand(const float* taps112, std::vector<uint16_t>& out);
+hipError_t download_w_tables(uint16_t* out);
 constexpr int kWideGroup = 64;    // channels per wave task of fir_w.hip
 constexpr int kFusedGroup = 16;   // channels per wave task of the fused kernel: a partly filled group costs as much as a full one
 

@@ -271,7 +271,11 @@ int atsc_hip_batch_timings(atsc_hip_encoder* enc, int batch, float* ms /* [ATSC_
 /* Constant tables as the library built them (host copies), for table parity tests:
  * which: 0 = 112 FIR taps (float), 1 = oscillator T0 (261248 complex64), 2 = scale (2 floats),
  *        3 = PRBS bytes (58344), 4 = field sync even (820 B), 5 = field sync odd (820 B),
- *        6 = RS generator g[0..20], 7 = the 112 half-symbol taps of the 2x form (float).  enc may be NULL (tables do not depend on the device; no GPU needed). */
+ *        6 = RS generator g[0..20], 7 = the 112 half-symbol taps of the 2x form (float),
+ *        8 = the matrix-core FIR's tap operand, fp16 bit patterns [phase 2][hi, lo][K-step 9][lane 64][8] (36864 B),
+ *        9 = the wide form's tap operand, fp16 bit patterns [hi, lo][K-step 8][lane 64][8] (16384 B).
+ * enc may be NULL (tables do not depend on the device; no GPU needed); for 8 and 9 a handle reads the operand back from
+ * its device, which is what the kernels multiply by (the error-budget tests use those bits). */
 int atsc_hip_get_table(atsc_hip_encoder* enc, int which, void* h_out, size_t bytes);
 
 const char* atsc_hip_error_string(int code);

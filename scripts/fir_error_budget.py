@@ -1,6 +1,33 @@
 #!/usr/bin/env python3
-"""Worst-case error of leaving low-order fp16 products out of the outer K-steps of k_mix_fir_mm (fir_fused.hip:
-tap_lo_needed / z_lo_needed), from the shipped taps' own fp16 remainders.  Needs the built library, no GPU."""
+"""Worst-case error of the two matrix-core FIR forms against the exactly evaluated sum_k taps[k] * T[i+k] * x[i+k], EVERY
+term of it, computed from the tap operand the kernels multiply by (atsc_hip_get_table ids 8 / 9: with a handle the bits
+are read back from the device, without one they come from the host function whose output create() uploads; no GPU needed
+for the latter).
+
+k_mix_fir_mm (fir_fused.hip):  y = Ahi.Zhi + [Alo.Zhi, K-steps 2..6] + [Ahi.Zlo, K-steps 1..7], fp32 accumulation
+  taps * 2^16 = Ahi + Alo (+ ra),  z * 2^12 = level * (Th + Tl + rt) = Zhi + Zlo (+ rz)
+    a. tap correction left out (K-steps 0, 1, 7, 8):    |z|max * sum |a - Ahi|                      (the shipped remainders)
+    b. tap residual where it is kept (K-steps 2..6):    |z|max * sum |a - Ahi - Alo|
+    c. z correction left out (K-steps 0, 8):            |z|max * (2^-10 + 2^-21) * sum |Ahi|        (|T' - Th| <= 2^-11 |T'|, |lv Th - Zhi| <= 2^-11 |lv Th|)
+    d. z split residual (K-steps 1..7):                 |z|max * 3 * 2^-22 * sum (|Ahi| [+ |Alo|])  (|T' - Th - Tl| <= 2^-22 |T'|; Zlo = fl16(lv Tl + r), |Zlo| <= 2^-10 |z'|)
+    e. Alo.Zlo, never formed (K-steps 2..6):            |z|max * 2^-10 * sum |Alo|
+    f. fp32 accumulation along the chain of 21 MFMAs:   c * 2^-24 * sum over the chain of the bound on |partial sum|
+    g. fp16 underflow floor of the packed arithmetic:   3 operations x 2^-25 absolute in the scaled domain, x sum |a| / 2^12
+  the 2^-28 that undoes the two scales is a power of two: exact.
+
+k_mix_fir_w (fir_w.hip):  y = X.Whi + [X.Wlo, K-steps 1..6],  X = level * 2^-12 exact in one fp16 piece
+  taps * 2^8 = Ahi + Alo (+ ra),  T * 2^4 = Th + Tl (+ rt),  Whi = fl16(Ahi Th), r = Ahi Th - Whi (exact),
+  l = fl16(Ahi Tl + r), Wlo = fl16(Alo Th + l)
+    a. low-order piece left out (K-steps 0, 7):         |x T|max * sum (|a - Ahi| + 2^-10 |Ahi|)
+    b. kept (K-steps 1..6): residuals and roundings     |x T|max * sum (|a - Ahi - Alo| + 2^-11 |Alo| [Alo.Tl] + 6 * 2^-22 |Ahi| [rt, l, Wlo])
+    c. fp32 accumulation along the chain of 14 MFMAs
+    d. underflow floor: 4 operations x 2^-25 x |x|max * 2^-12 per element
+
+|T| : the oscillator recursion T_f = T_(f-1) (x) scale has |scale| = 1 - 1.5e-8, so |T_f| shrinks (0.98 |T_0| after 2^20
+fields); max |T_f| is taken over the first `fields` fields of the fp32 recursion (it is |T_0|'s own maximum to 1e-7).
+
+`c`: roundings per MFMA in units of 2^-24 |result|; scripts/ubench/mfma_round.hip measures it on the device
+(profiles/r03/ubench_mfma_round.txt)."""
 import os
 import sys
 
@@ -9,30 +36,162 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import atsc_amd  # noqa: E402
 
-ZMAX = 8.25 * 0.9          # |level + pilot| <= 8.25, |oscillator| = 0.9
-U = 2.0 ** -11             # unit roundoff of fp16
-A_SCALE = 65536.0          # kAScale
+LEVEL_MAX = 8.25           # |2 v - 7 + 1.25| <= 8.25 (signal.h:13-18)
+MFMA_ROUNDINGS = 2.0       # c: measured <= 1 ulp(D) = 2 x 2^-24 |D| per instruction (truncating adder), see the docstring
+TOLERANCE = 1e-5           # of full scale, BASELINE.json north_star
 
 
-def rows(v, n):
-    at = lambda t: v[t] if 0 <= t < n else 0.0
-    return np.array([[sum(at(k - p) for k in range(16 * ks, 16 * ks + 16)) for p in range(32)] for ks in range(9)])
+def osc_max(fields=64):
+    """max |T_f[m]| over the first `fields` fields of the reference's fp32 recursion (offset.h:35-41)."""
+    t = atsc_amd.get_table(1).reshape(-1, 2).astype(np.float32)
+    sc = atsc_amd.get_table(2).astype(np.float32)
+    re, im = t[:, 0].copy(), t[:, 1].copy()
+    worst = float(np.hypot(re.astype(np.float64), im.astype(np.float64)).max())
+    for _ in range(1, fields):
+        re, im = re * sc[0] - im * sc[1], re * sc[1] + im * sc[0]
+        worst = max(worst, float(np.hypot(re.astype(np.float64), im.astype(np.float64)).max()))
+    return worst
+
+
+def fused_operand(handle=None):
+    """-> hi, lo [phase][K-step 9][row 32][k 16] in tap units, and the true taps in the same layout."""
+    bits = atsc_amd.get_table(8, handle)
+    op = bits.view(np.float16).astype(np.float64).reshape(2, 2, 9, 64, 8) / 65536.0
+    taps = [atsc_amd.get_table(0).astype(np.float64)[:111], atsc_amd.get_table(7).astype(np.float64)[:112]]
+    hi = np.zeros((2, 9, 32, 16))
+    lo = np.zeros_like(hi)
+    true = np.zeros_like(hi)
+    for ph in range(2):
+        for lane in range(64):
+            p, h = lane & 31, lane >> 5
+            hi[ph, :, p, 8 * h:8 * h + 8] = op[ph, 0, :, lane, :]
+            lo[ph, :, p, 8 * h:8 * h + 8] = op[ph, 1, :, lane, :]
+        n = len(taps[ph])
+        for ks in range(9):
+            for p in range(32):
+                for k in range(16):
+                    idx = 16 * ks + k - p
+                    true[ph, ks, p, k] = taps[ph][idx] if 0 <= idx < n else 0.0
+    return hi, lo, true
+
+
+def wide_operand(handle=None):
+    """-> hi, lo [K-step 8][output 16][k 16] in tap units (the re and im rows of an output hold the same taps: both are
+    checked to agree), and the true taps."""
+    bits = atsc_amd.get_table(9, handle)
+    op = bits.view(np.float16).astype(np.float64).reshape(2, 8, 64, 8) / 256.0
+    taps = atsc_amd.get_table(0).astype(np.float64)[:111]
+    hi = np.zeros((8, 16, 16))
+    lo = np.zeros_like(hi)
+    true = np.zeros_like(hi)
+    for lane in range(64):
+        p, comp, h = (lane & 31) >> 1, lane & 1, lane >> 5
+        if comp == 0:
+            hi[:, p, 8 * h:8 * h + 8] = op[0, :, lane, :]
+            lo[:, p, 8 * h:8 * h + 8] = op[1, :, lane, :]
+        else:
+            assert np.array_equal(hi[:, p, 8 * h:8 * h + 8], op[0, :, lane, :]) and np.array_equal(lo[:, p, 8 * h:8 * h + 8], op[1, :, lane, :])
+    for ks in range(8):
+        for p in range(16):
+            for k in range(16):
+                idx = 16 * ks + k - p
+                true[ks, p, k] = taps[idx] if 0 <= idx < 111 else 0.0
+    return hi, lo, true
+
+
+def fused_budget(phase, tap_lo=range(2, 7), z_lo=range(1, 8), handle=None, fields=64, c=MFMA_ROUNDINGS):
+    """Every term of k_mix_fir_mm's error for one output phase, worst output row, in units of full scale."""
+    hi, lo, true = fused_operand(handle)
+    hi, lo, true = hi[phase], lo[phase], true[phase]
+    zmax = LEVEL_MAX * osc_max(fields)
+    tap_lo, z_lo = set(tap_lo), set(z_lo)
+    rows = lambda v, sel: np.abs(v)[sorted(sel)].sum(axis=(0, 2)) if sel else np.zeros(32)
+    all_ks = set(range(9))
+    t = {}
+    t["a tap correction left out"] = zmax * rows(true - hi, all_ks - tap_lo)
+    t["b tap residual"] = zmax * rows(true - hi - lo, tap_lo)
+    t["c z correction left out"] = zmax * (2.0 ** -10 + 2.0 ** -21) * rows(hi, all_ks - z_lo)
+    t["d z split residual"] = zmax * 3 * 2.0 ** -22 * (rows(hi, z_lo) + rows(lo, z_lo & tap_lo))
+    t["e Alo.Zlo never formed"] = zmax * 2.0 ** -10 * rows(lo, tap_lo & z_lo)
+    # the chain: per K-step hi.hi, [lo.hi], [hi.lo]; the partial sum after an MFMA is bounded by everything accumulated so far
+    acc = np.zeros(32)
+    partial = np.zeros(32)
+    for ks in range(9):
+        parts = [zmax * np.abs(hi[ks]).sum(axis=1)]
+        if ks in tap_lo:
+            parts.append(zmax * np.abs(lo[ks]).sum(axis=1))
+        if ks in z_lo:
+            parts.append(zmax * 2.0 ** -10 * np.abs(hi[ks]).sum(axis=1))
+        for q in parts:
+            partial = partial + q
+            acc = acc + c * 2.0 ** -24 * partial
+    t["f fp32 accumulation"] = acc
+    t["g fp16 underflow floor"] = 3 * 2.0 ** -25 / 4096.0 * (1 + LEVEL_MAX) * np.abs(true).sum(axis=(0, 2)) * 0 + \
+        3 * 2.0 ** -25 / 4096.0 * (1 + LEVEL_MAX) * np.abs(hi).sum(axis=(0, 2))
+    total = sum(t.values())
+    return float(total.max()), {k: float(v.max()) for k, v in t.items()}
+
+
+def wide_budget(lo_steps=range(1, 7), handle=None, fields=64, c=MFMA_ROUNDINGS):
+    """Every term of k_mix_fir_w's error, worst output row, in units of full scale."""
+    hi, lo, true = wide_operand(handle)
+    xt = LEVEL_MAX * osc_max(fields)
+    lo_steps = set(lo_steps)
+    all_ks = set(range(8))
+    rows = lambda v, sel: np.abs(v)[sorted(sel)].sum(axis=(0, 2)) if sel else np.zeros(16)
+    t = {}
+    t["a low-order piece left out"] = xt * (rows(true - hi, all_ks - lo_steps) + 2.0 ** -10 * rows(hi, all_ks - lo_steps))
+    t["b residuals and roundings where kept"] = xt * (rows(true - hi - lo, lo_steps) + 2.0 ** -11 * rows(lo, lo_steps) +
+                                                      6 * 2.0 ** -22 * rows(hi, lo_steps))
+    acc = np.zeros(16)
+    partial = np.zeros(16)
+    for ks in range(8):
+        parts = [xt * np.abs(hi[ks]).sum(axis=1)]
+        if ks in lo_steps:
+            parts.append(xt * 3 * 2.0 ** -11 * np.abs(hi[ks]).sum(axis=1))
+        for q in parts:
+            partial = partial + q
+            acc = acc + c * 2.0 ** -24 * partial
+    t["c fp32 accumulation"] = acc
+    # absolute floor of 4 fp16 operations per element of W (2^-25 in the scaled domain; W' = W * 2^12), 126 elements per row
+    t["d fp16 underflow floor"] = np.full(16, 4 * 2.0 ** -25 / 4096.0 * LEVEL_MAX * 126)
+    total = sum(t.values())
+    return float(total.max()), {k: float(v.max()) for k, v in t.items()}
 
 
 def budget(table, n, tap_skip, z_skip):
-    h = atsc_amd.get_table(table).astype(np.float32).ravel()[:n] * np.float32(A_SCALE)
-    hi = h.astype(np.float16)
-    lo = (h - hi.astype(np.float32)).astype(np.float16)
-    a_lo = rows(np.abs(lo.astype(np.float64)) / A_SCALE, n)
-    a_hi = rows(np.abs(hi.astype(np.float64)) / A_SCALE, n)
-    tap_part = ZMAX * a_lo[list(tap_skip)].sum(0)
-    z_part = ZMAX * 2 * U * a_hi[list(z_skip)].sum(0)
+    """Round 2's two-term figure (terms a + c of fused_budget), kept for DESIGN.md's table of skip sets."""
+    phase = 0 if table == 0 else 1
+    hi, lo, true = fused_operand()
+    zmax = LEVEL_MAX * 0.9
+    tap_part = zmax * np.abs(true[phase] - hi[phase])[list(tap_skip)].sum(axis=(0, 2))
+    z_part = zmax * 2.0 ** -10 * np.abs(hi[phase])[list(z_skip)].sum(axis=(0, 2))
     return float((tap_part + z_part).max()), float(tap_part.max()), float(z_part.max())
 
 
+def report(handle=None, fields=64):
+    out = {}
+    for name, fn in (("k_mix_fir_mm, symbol phase", lambda: fused_budget(0, handle=handle, fields=fields)),
+                     ("k_mix_fir_mm, half-symbol phase (2x form)", lambda: fused_budget(1, handle=handle, fields=fields)),
+                     ("k_mix_fir_w", lambda: wide_budget(handle=handle, fields=fields))):
+        total, terms = fn()
+        out[name] = (total, terms)
+    return out
+
+
 if __name__ == "__main__":
-    for name, table, n in (("symbol phase", 0, 111), ("half-symbol phase", 7, 112)):
-        for tap_skip, z_skip in (((0, 1, 7, 8), (0, 8)), ((0, 1, 7, 8), (0, 1, 7, 8))):
-            total, tp, zp = budget(table, n, tap_skip, z_skip)
-            print(f"{name}: tap correction skipped in K-steps {tap_skip}, z correction in {z_skip}: "
-                  f"worst case {total:.2e} of full scale (taps {tp:.2e}, z {zp:.2e})")
+    print(f"max |T_f| over 64 fields: {osc_max(64):.9f}; c = {MFMA_ROUNDINGS} roundings of 2^-24 per MFMA")
+    for name, (total, terms) in report().items():
+        print(f"{name}: worst case {total:.3e} of full scale ({'inside' if total < TOLERANCE else 'OUTSIDE'} {TOLERANCE:g})")
+        for k, v in terms.items():
+            print(f"    {k:40s} {v:.3e}")
+    print("alternative skip sets of k_mix_fir_mm (symbol phase / half-symbol phase):")
+    for tap_lo, z_lo in ((range(2, 7), range(1, 8)), (range(2, 7), range(2, 7)), (range(1, 8), range(1, 8)), (range(2, 7), range(0, 9)),
+                         (range(1, 7), range(1, 8)), (range(2, 8), range(1, 8)), (range(0, 9), range(0, 9))):
+        a = fused_budget(0, tap_lo, z_lo)[0]
+        b = fused_budget(1, tap_lo, z_lo)[0]
+        n = 9 + len(tap_lo) + len(z_lo)
+        print(f"    tap correction in K-steps {min(tap_lo)}..{max(tap_lo)}, z correction in {min(z_lo)}..{max(z_lo)} ({n} MFMAs): {a:.3e} / {b:.3e}")
+    print("alternative skip sets of k_mix_fir_w:")
+    for lo_steps in (range(1, 7), range(2, 6), range(0, 8), range(1, 8), range(0, 7)):
+        print(f"    low-order product in K-steps {min(lo_steps)}..{max(lo_steps)} ({8 + len(lo_steps)} MFMAs per block): {wide_budget(lo_steps)[0]:.3e}")

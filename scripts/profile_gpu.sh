@@ -2,11 +2,11 @@
 # Run ON THE GPU BOX (through gpurun): kernel-trace stats + PMC passes for bench.py.
 # Usage: scripts/profile_gpu.sh <tag>      -> gpurun_out/prof_<tag>/...   (summarise with scripts/summarize_profile.py)
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $PWD/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
 # the trace pass runs the default bench (its own step and warm-up counts) so that its per-kernel averages are those of bench.py's own line
 BENCH_TRACE="python3 $PWD/bench.py --no-cpu-baseline"
 cd /tmp
