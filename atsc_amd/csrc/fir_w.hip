@@ -14,7 +14,7 @@
 //     and shared by the 64 channels of the wave (two 32-channel row blocks).
 //   * N = 32 columns = 16 consecutive outputs x (re, im), K = 128 = eight K-steps of v_mfma_f32_32x32x16_f16 (16 + 110 inputs
 //     feed a tile): 8 products with Whi and 6 with Wlo (the taps of K-steps 0 and 7 sum to < 0.00065 per row: their low-order
-//     piece is worth 2.3e-6 of full scale at most, scripts/fir_error_budget.py) = 14 MFMAs per 32 channels x 16 outputs,
+//     piece is worth 5.5e-6 of full scale at most, scripts/fir_error_budget.py) = 14 MFMAs per 32 channels x 16 outputs,
 //     28 per 32 x 32 against 42.
 //   * W is the A operand (row 2 p + comp), the levels the B operand (column = channel): a lane of the accumulator tile is a
 //     CHANNEL and four consecutive registers are two consecutive samples (re, im, re, im) = 16 contiguous bytes of that
@@ -36,9 +36,10 @@
 //
 // Where it stands (64 channels x 64 fields): 1.99 ms per launch against k_mix_fir_mm's 1.86 -- a third fewer matrix
 // products, but the per-tile W (104 packed fp16 instructions) and the producer of 64 channels cost the SIMD as many issue
-// cycles as the products saved; the board draws 1314 W at 2.3 GHz here against 1400 W (its cap) at 1.9-2.0 GHz there.  Its error
-// bound is tighter (3.7e-6 of full scale worst case by construction, 1.2e-6 measured, against 7.1e-6 / 1.5e-6), so it is kept as
-// the form to ask for when the margin matters (ATSC_HIP_FIR_WIDE); AUTO stays with k_mix_fir_mm.
+// cycles as the products saved; the board draws 1314 W at 2.3 GHz here against 1400 W (its cap) at 1.9-2.0 GHz there.  Its
+// measured error is the lowest of the matrix-core forms (1.2e-6 of full scale against 1.7e-6); its worst case with every
+// term at its bound is not (8.4e-6 against 7.2e-6, scripts/fir_error_budget.py).  Kept as the measured alternative
+// (ATSC_HIP_FIR_WIDE); AUTO stays with k_mix_fir_mm.
 #include "iq_format.h"
 #include "kernels.h"
 #include "trellis_bits.h"

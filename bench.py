@@ -44,10 +44,11 @@ CHAIN_BYTES_PER_SYM = 8.225    # whole chain fused minimum (58656 B in + 2083328
 FIELD_SYMBOLS = 313 * 832
 FUSED_DTYPE = ("f32 (oscillator recursion and accumulation in fp32; the mixer product and the FIR's multiplies run on two "
                "fp16 pieces of each fp32 operand, matrix cores; the low-order pieces are left out for the outermost taps: "
-               "1.5e-6 of full scale measured, 7.1e-6 worst case by construction, tolerance 1e-5)")
+               "1.7e-6 of full scale measured, 7.2e-6 worst case over every input with every error term at its bound "
+               "(scripts/fir_error_budget.py), tolerance 1e-5)")
 WIDE_DTYPE = ("f32 (oscillator recursion and accumulation in fp32; the tap x oscillator operand is formed per tile in two fp16 pieces, "
               "the levels are exact in one, matrix cores; the low-order piece is left out for the two outermost K-steps: 1.2e-6 of "
-              "full scale measured, 3.7e-6 worst case by construction, tolerance 1e-5)")
+              "full scale measured, 8.4e-6 worst case with every error term at its bound, tolerance 1e-5)")
 METRIC = "real-time ATSC channels per GPU (Msym/s; 10.76=1 ch) at 1/2/4/8 MI355X"
 PROFILE_ROUND = "r03"
 PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)

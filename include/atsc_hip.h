@@ -141,7 +141,8 @@ size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown form
 /* Which kernel computes offset.process_field + filter.process_field (src/atsc/atsc.cpp:85-86).  Both are parity-checked
  * against the same oracle to the same tolerance (1e-5 of full scale); their outputs agree to ~2e-6 of full scale but are not
  * bit-identical.  FFT is fp32 throughout (2.4e-7 against the oracle); the matrix-core forms multiply fp16 pieces of both
- * operands with fp32 accumulation: 1.5e-6 measured, 7.1e-6 worst case over every input by construction (fir_fused.hip).
+ * operands with fp32 accumulation: 1.7e-6 measured, 7.2e-6 worst case over every input with every error term at its
+ * bound (fir_fused.hip, scripts/fir_error_budget.py).
  *   FFT : overlap-save fast convolution on the vector units (any channel count)
  *   MFMA: banded GEMM on the matrix cores; needs the oscillator shared by many channels to pay off
  *   FUSED: the MFMA form with the trellis / map / sync stage (src/atsc/atsc.cpp:83-84) fused in: the symbols are
@@ -150,9 +151,9 @@ size_t atsc_hip_iq_sample_bytes(int format); /* 8 / 4 / 2; 0 for an unknown form
  *         written anywhere and atsc_hip_stage_buffer(TRELLIS_MAP) returns ATSC_HIP_ERR_STATE)
  *   WIDE: FUSED with the oscillator folded into the TAP operand instead of the sample operand (fir_w.hip): the levels are
  *         exact in one fp16 piece, so a third fewer matrix products, shared by 64 channels per wave; complex64 at one sample
- *         per symbol and a channel count that is a multiple of 64 only (ATSC_HIP_ERR_ARG otherwise); 3.7e-6 worst case by
- *         construction, 1.2e-6 measured -- the tightest of the matrix-core forms -- at 7 % more time than FUSED on 64 channels
- *         x 64 fields.  Never AUTO's choice: ask for it when the margin matters.
+ *         per symbol and a channel count that is a multiple of 64 only (ATSC_HIP_ERR_ARG otherwise); 1.2e-6 measured (the
+ *         lowest of the matrix-core forms), 8.4e-6 worst case with every term at its bound, 7 % more time than FUSED on
+ *         64 channels x 64 fields and 6 % less board power.  Never AUTO's choice; kept as the measured alternative.
  *   AUTO: FUSED when the handle's
  *         channels fill at least 80 % of whole groups of 16 (13..16, 26..32, 39..48, 52..),
  *         FFT otherwise (default)

@@ -189,3 +189,87 @@ def test_wide_form_symbols_and_iq(torch_cuda, C_, nf):
         got_iq = np.concatenate([outs["wide"][b][1][c].reshape(-1).cpu().numpy() for b in range(2)])
         assert np.array_equal(got_sym, want["sym"])
         assert np.abs(got_iq - want["iq"]).max() <= IQ_TOL
+
+
+def _model_field(sym_row, t_field, taps):
+    """float64: sum_k taps[k] z[i + k], z = fl32(level * T) per component (offset.h:24-31), on the field followed by the copy of
+    its first segment (field_sync.h:16)."""
+    s = sym_row.astype(np.float64)
+    lv = 2.0 * np.concatenate([s, s[:832]]) - 5.75
+    n = lv.size
+    zr = (lv * t_field[:n, 0].astype(np.float64)).astype(np.float32).astype(np.float64)
+    zi = (lv * t_field[:n, 1].astype(np.float64)).astype(np.float32).astype(np.float64)
+    t = taps.astype(np.float64)
+    return np.stack([np.correlate(zr, t, "valid")[:FIELD_SYMBOLS], np.correlate(zi, t, "valid")[:FIELD_SYMBOLS]], axis=1)
+
+
+@pytest.mark.parametrize("C_,field,up", [(16, 0, 1), (64, 63, 1), (16, 63, 2)])
+def test_matrix_core_fir_against_chosen_symbols_field_and_phase(torch_cuda, C_, field, up):
+    """VERDICT r2 item 5.  k_mix_fir_mm leaves low-order fp16 products out of its outer K-steps; scripts/fir_error_budget.py
+    bounds every term of what that and the fp16 pieces can cost.  Here (a) the budget is recomputed from the operand READ BACK
+    from the device (atsc_hip_get_table id 8 with a handle), and (b) the symbols are chosen against the kernel -- a float64
+    restatement of its omitted terms (tests/fir_adversary.py) picks, for a target every 161 outputs, the level of every input
+    of the outer K-steps that pushes the error one way -- at field 63 (T_63, not T_0), on a 64-channel handle (four wave
+    groups), and for the half-symbol operand of the 2x form (odd samples).  The result stays inside 1e-5 of the float64
+    model everywhere, inside 1e-5 of the oracle on the channels compared, and the error AT the targets is the one aimed for
+    (the restatement describes the kernel)."""
+    import fir_adversary as adv
+    torch = torch_cuda
+    enc = atsc_amd.Encoder(channels=C_, max_fields=1)
+    enc.set_fir_form(atsc_amd.FIR_MFMA)
+    enc.set_upsample(up)
+    # (a) the operand the kernels of this device multiply by = the host-built one, bit for bit; the budget from those bits
+    dev_bits = atsc_amd.get_table(8, enc.h)
+    assert np.array_equal(dev_bits, atsc_amd.get_table(8)), "device copy of the tap operand differs from the host build"
+    assert np.array_equal(atsc_amd.get_table(9, enc.h), atsc_amd.get_table(9))
+    operand = adv.operand(enc.h)
+    for ph in range(up):
+        total, terms = adv.feb.fused_budget(ph, handle=enc.h, fields=max(field + 1, 2), c=1.0)
+        print(f"phase {ph}: budget from the device operand {total:.3e}", {k[:1]: f"{v:.2e}" for k, v in terms.items()})
+        assert total < IQ_TOL
+    # the oscillator of this field from the oracle's own recursion (mix_fir on dummy symbols moves it on)
+    o = Oracle()
+    if field:
+        o.mix_fir(np.zeros(field * FIELD_SYMBOLS, np.uint8), field)
+    t_field = o.osc_table().reshape(-1, 2).astype(np.float32)
+    rng = np.random.default_rng(5 + field + up)
+    sym = rng.integers(0, 8, (C_, FIELD_SYMBOLS), dtype=np.uint8)
+    targets = []
+    for c in range(C_):
+        for n_t, i in enumerate(range(1000 + 7 * c, FIELD_SYMBOLS - 400, 161 * max(1, C_ // 16))):
+            comp, ph = (c + n_t) & 1, (n_t >> 1) % up
+            sign = 1.0 if (n_t >> 2) & 1 else -1.0
+            aimed = adv.choose(sym, c, i // 32, i % 32, comp, t_field, ph, operand, sign)
+            targets.append((c, i, comp, ph, aimed))
+    if field:
+        enc.seek(field)
+    d_sym = torch.from_numpy(sym).cuda()
+    d_iq = torch.empty((C_, up * FIELD_SYMBOLS), dtype=torch.complex64, device="cuda")
+    enc.mix_fir(d_sym.data_ptr(), 1, d_iq.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_iq.cpu().numpy().view(np.float32).reshape(C_, FIELD_SYMBOLS, up, 2).astype(np.float64)
+    taps = [atsc_amd.get_table(0)[:111], atsc_amd.get_table(7)[:112]]
+    t = np.array([(c, i, comp, ph) for c, i, comp, ph, _ in targets])
+    aimed = np.array([a for *_, a in targets])
+    worst = 0.0
+    err_at = np.zeros(len(targets))
+    for c in range(C_):
+        for ph in range(up):
+            diff = got[c, :, ph, :] - _model_field(sym[c], t_field, taps[ph])
+            worst = max(worst, float(np.abs(diff).max()))
+            sel = np.nonzero((t[:, 0] == c) & (t[:, 3] == ph))[0]
+            err_at[sel] = -diff[t[sel, 1], t[sel, 2]]     # `aimed` is exact minus kernel
+    print(f"C={C_} field={field} up={up}: max |error| vs the float64 model {worst:.3e}; at the {len(targets)} targets: aimed "
+          f"{np.abs(aimed).max():.3e} max / {np.abs(aimed).mean():.3e} mean, seen {np.abs(err_at).max():.3e} max, "
+          f"|seen - aimed| {np.abs(err_at - aimed).max():.3e} max")
+    assert worst <= IQ_TOL
+    assert np.abs(aimed).max() > 1.5e-6                     # the vector does what it is built for (random data: 1.5e-6 over 1e9 samples)
+    assert np.abs(err_at - aimed).max() < 2.0e-6            # and the restatement is the kernel: the rest is the inner K-steps' residue
+    assert np.corrcoef(err_at, aimed)[0, 1] > 0.8
+    # against the oracle's fp32 FIR (the pinned half: phase 0) on two channels
+    for c in sorted({0, C_ - 1}):
+        oc = Oracle()
+        if field:
+            oc.mix_fir(np.zeros(field * FIELD_SYMBOLS, np.uint8), field)
+        want = oc.mix_fir(sym[c], 1).reshape(FIELD_SYMBOLS, 2)
+        assert np.abs(got[c, :, 0, :] - want).max() <= IQ_TOL
