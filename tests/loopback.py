@@ -197,3 +197,67 @@ def viterbi_symbols(levels, fields):
     v = 4 * z2 + lo
     sliced = levels.round().clamp(0, 7).to(torch.uint8)      # segment / field syncs: nearest level (not decoded further)
     return _from_per_encoder(v.to(torch.uint8), sliced, fields)
+
+
+# ---- IQ front end: complex baseband samples -> soft symbol levels.  Written from the A/53 signal definition (suppressed
+# carrier VSB: real 8-level symbols + 1.25 pilot, root-raised-cosine Nyquist filtering with roll-off 0.1152, here at one
+# complex sample per symbol with the carrier at phi = 2 pi (309411 - 3000000) / fs rad per sample) and NOT from
+# the product's tables or the oracle: its own pulse (255 taps, not the modulator's 111), an ideal double-precision carrier,
+# and a per-field data-aided estimate of the complex gain in place of the carrier / AGC loops of a real receiver (the
+# reference's oscillator is not an ideal NCO: its phase walks off the ideal one by 0.4 rad over 64 fields, SURVEY.md
+# "Hard parts", which is exactly what a receiver's carrier recovery absorbs).
+ROLL_OFF = 0.1152
+CARRIER_PHI = 2.0 * np.pi * (309411.0 - 3000000.0) / (4500000.0 / 286 * 684)
+TX_DELAY = 55                      # the modulator's y[i] is centred on symbol i + 55 (111 taps)
+
+
+def rrc_pulse(u, alpha=ROLL_OFF):
+    """root-raised-cosine pulse, u in pulse periods (unit energy scaling left to the gain estimate)"""
+    u = np.asarray(u, np.float64)
+    out = np.empty_like(u)
+    for idx, t in np.ndenumerate(u):
+        if abs(t) < 1e-12:
+            out[idx] = 1.0 - alpha + 4.0 * alpha / np.pi
+        elif abs(abs(4.0 * alpha * t) - 1.0) < 1e-9:
+            out[idx] = alpha / np.sqrt(2.0) * ((1 + 2 / np.pi) * np.sin(np.pi / (4 * alpha)) + (1 - 2 / np.pi) * np.cos(np.pi / (4 * alpha)))
+        else:
+            out[idx] = (np.sin(np.pi * t * (1 - alpha)) + 4 * alpha * t * np.cos(np.pi * t * (1 + alpha))) / (np.pi * t * (1 - (4 * alpha * t) ** 2))
+    return out
+
+
+def receive_iq(iq, fields, half_symbol_late=False, half_len=127):
+    """iq: complex64 tensor [fields*260416], one sample per symbol, of ONE stream from its first field on (the modulator's
+    output; with half_symbol_late=True the samples taken half a symbol after those, i.e. the odd samples of the 2x output).
+    Returns float64 [fields*260416] soft levels in level-index units (a clean symbol v arrives as ~float(v)) for
+    viterbi_symbols / decode_symbols.  Steps: matched filter (the lowpass pulse of period two samples; for the late
+    stream sampled half a sample off, which puts the output back on the symbol instants), ideal carrier removed, per-field
+    complex gain from the pilot then refined against the sliced symbols, real part -> level index."""
+    dev = iq.device
+    n = fields * FIELD_SYMS
+    assert iq.numel() == n
+    k = np.arange(2 * half_len + 1) - half_len + (0.5 if half_symbol_late else 0.0)
+    g = rrc_pulse(k / 2.0)
+    y = iq.to(torch.complex128)
+    r = torch.zeros(n, dtype=torch.complex128, device=dev)                           # r[i] = sum_j g[j] y[i + j - half_len] <-> symbol i + TX_DELAY
+    for j, gj in enumerate(g):                                                        # (shifted adds: no float64 convolution on every backend)
+        s = j - half_len
+        if s >= 0:
+            r[:n - s].add_(y[s:], alpha=float(gj))
+        else:
+            r[-s:].add_(y[:n + s], alpha=float(gj))
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    for f in range(fields):
+        lo, hi = f * FIELD_SYMS, min((f + 1) * FIELD_SYMS, n - TX_DELAY)
+        sym_idx = torch.arange(lo, hi, device=dev, dtype=torch.float64)
+        ph = (sym_idx * CARRIER_PHI) % (2.0 * np.pi)
+        d = r[lo - TX_DELAY if lo else 0:hi - TX_DELAY]
+        if lo == 0:
+            d = torch.cat([torch.zeros(TX_DELAY, dtype=d.dtype, device=dev), d])[:hi - lo]   # the stream's first 55 symbols: not received
+        d = d * torch.polar(torch.ones_like(ph), -ph)
+        a = d.mean() / 1.25                                                                # pilot: the only DC in the signal
+        for _ in range(2):
+            lv = (d / a).real
+            dec = (((lv - 1.25 + 7.0) / 2.0).round().clamp(0, 7) * 2.0 - 7.0 + 1.25)
+            a = (d * dec).sum() / (dec * dec).sum()                                        # least squares d ~ a * level
+        out[lo:hi] = ((d / a).real - 1.25 + 7.0) / 2.0
+    return out

@@ -273,3 +273,76 @@ def test_matrix_core_fir_against_chosen_symbols_field_and_phase(torch_cuda, C_, 
             oc.mix_fir(np.zeros(field * FIELD_SYMBOLS, np.uint8), field)
         want = oc.mix_fir(sym[c], 1).reshape(FIELD_SYMBOLS, 2)
         assert np.abs(got[c, :, 0, :] - want).max() <= IQ_TOL
+
+
+def test_iq_loopback_full_size_symbol_rate(torch_cuda):
+    """the loop-back closed at the IQ, through the mixer and the FIR.  BASELINE config 4's per-GPU shard, 64
+    DISTINCT random streams x 64 fields through the default (fused matrix-core) path; every channel's complex64 IQ goes
+    through tests/loopback.py's receiver -- its own 255-tap matched filter, an ideal double-precision carrier, per-field
+    gain from the pilot, slicer -- and the existing de-interleave / RS / de-randomize chain, and gives back the TS that went in
+    with every RS codeword valid; the soft levels sit within 0.1 of a level step of the 8 levels.  On four channels the
+    Viterbi decoder then takes the same IQ with noise added to it.  No oracle, no product table."""
+    from loopback import decode_symbols, receive_iq, viterbi_symbols
+    torch = torch_cuda
+    C_, nf = 64, 64
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4242)
+    ts = torch.randint(0, 256, (C_, nf * 312, 188), dtype=torch.uint8, device="cuda", generator=g)
+    ts[:, :, 0] = 0x47
+    enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    n = nf * FIELD_SYMBOLS
+    d_iq = torch.empty((C_, n), dtype=torch.complex64, device="cuda")
+    enc.encode_batch(ts.data_ptr(), nf, None, d_iq.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert enc.fir_form() == atsc_amd.FIR_FUSED
+    worst_soft = 0.0
+    for c in range(C_):
+        lv = receive_iq(d_iq[c], nf)
+        hard = lv.round().clamp(0, 7)
+        worst_soft = max(worst_soft, float((lv - hard)[64:n - 400].abs().max()))
+        payload, worst = decode_symbols(hard.to(torch.uint8), nf)
+        assert worst == 0, f"channel {c}: RS syndromes not zero"
+        assert bool((payload == ts[c, :(nf - 1) * 312, 1:]).all()), f"channel {c}: TS recovered from the IQ differs"
+    print(f"soft levels: at most {worst_soft:.3f} of a level step from a level")
+    assert worst_soft < 0.15
+    k = 4
+    for c in (0, 21, 42, 63):
+        rx = d_iq[c, :k * FIELD_SYMBOLS]
+        g.manual_seed(100 + c)
+        noise = torch.randn((2, rx.numel()), generator=g, dtype=torch.float32, device="cuda")
+        rx = rx + 0.03 * torch.complex(noise[0], noise[1])           # 0.24 of a level step rms at the slicer: it errs on 3 % of the symbols
+        lv = receive_iq(rx, k)
+        payload, worst = decode_symbols(viterbi_symbols(lv, k), k)
+        assert worst == 0 and bool((payload == ts[c, :(k - 1) * 312, 1:]).all()), f"channel {c}: noisy IQ not recovered"
+
+
+def test_iq_loopback_odd_samples_of_the_2x_form(torch_cuda):
+    """The same from the interpolating form, using ONLY the odd samples y2[2 i + 1] (the half-symbol operand: the samples the
+    reference has no counterpart for, include/atsc_hip.h atsc_hip_set_upsample): 16 streams x 4 fields; the receiver's pulse is
+    sampled half a sample off, which puts its output back on the symbol instants; Viterbi, de-interleave, RS -> the TS that
+    went in.  A wrong half-symbol operand (pulse, scale, alignment) cannot pass: the symbols would not be there."""
+    from loopback import decode_symbols, receive_iq, viterbi_symbols
+    torch = torch_cuda
+    C_, nf = 16, 4
+    g = torch.Generator(device="cuda")
+    g.manual_seed(777)
+    ts = torch.randint(0, 256, (C_, nf * 312, 188), dtype=torch.uint8, device="cuda", generator=g)
+    ts[:, :, 0] = 0x47
+    enc = atsc_amd.Encoder(channels=C_, max_fields=nf)
+    enc.set_upsample(2)
+    n = nf * FIELD_SYMBOLS
+    d_iq = torch.empty((C_, 2 * n), dtype=torch.complex64, device="cuda")
+    enc.encode_batch(ts.data_ptr(), nf, None, d_iq.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    worst_soft = 0.0
+    for c in range(C_):
+        lv = receive_iq(d_iq[c, 1::2].contiguous(), nf, half_symbol_late=True)
+        worst_soft = max(worst_soft, float((lv - lv.round().clamp(0, 7))[64:n - 400].abs().max()))
+        payload, worst = decode_symbols(viterbi_symbols(lv, nf), nf)
+        assert worst == 0, f"channel {c}: RS syndromes not zero"
+        assert bool((payload == ts[c, :(nf - 1) * 312, 1:]).all()), f"channel {c}: TS recovered from the odd samples differs"
+        if c == 0:   # and the even samples are the symbol-rate signal
+            p0, w0 = decode_symbols(receive_iq(d_iq[c, 0::2].contiguous(), nf).round().clamp(0, 7).to(torch.uint8), nf)
+            assert w0 == 0 and bool((p0 == ts[c, :(nf - 1) * 312, 1:]).all())
+    print(f"odd samples: soft levels at most {worst_soft:.3f} of a level step from a level")
+    assert worst_soft < 0.15

@@ -161,3 +161,19 @@ def test_loopback_viterbi_decodes_a_noisy_signal():
     dec = viterbi_symbols(rx, nf)
     sliced = rx.round().clamp(0, 7).to(torch.uint8)
     assert int((dec != clean)[data].sum()) * 3 < int((sliced != clean)[data].sum())
+
+
+def test_loopback_receiver_recovers_the_ts_from_the_oracles_iq():
+    """tests/loopback.py: receive_iq (own matched filter, ideal carrier, pilot gain) + slicer + decode_symbols on the oracle's
+    complex64 IQ of three fields gives the TS back: the verifier's IQ front end is right before the GPU tests lean on it."""
+    import torch
+    from loopback import decode_symbols, receive_iq
+    nf = 3
+    ts = ts_mt(5, nf)
+    w = Oracle().process_fields(ts, nf, want=("sym", "iq"))
+    lv = receive_iq(torch.from_numpy(w["iq"].view(np.complex64).copy()), nf)
+    sym = torch.from_numpy(w["sym"].astype(np.int64))
+    assert float((lv - sym.double())[64:-400].abs().max()) < 0.15
+    payload, worst = decode_symbols(lv.round().clamp(0, 7).to(torch.uint8), nf)
+    assert worst == 0
+    assert bool((payload == torch.from_numpy(ts.reshape(nf * 312, 188)[:(nf - 1) * 312, 1:].copy())).all())
