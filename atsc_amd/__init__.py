@@ -38,7 +38,7 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
            "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_mix_fir_static", "atsc_hip_export_state", "atsc_hip_import_state", "atsc_hip_seek",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
            "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form", "atsc_hip_set_upsample", "atsc_hip_get_upsample",
-           "atsc_hip_process_chunked",
+           "atsc_hip_process_chunked", "atsc_hip_process_multi", "atsc_hip_multi_pending",
            "atsc_hip_error_string", "atsc_hip_version",
            # include/atsc_hip_resample.h
            "atsc_hip_resampler_design", "atsc_hip_resampler_create", "atsc_hip_resampler_destroy",
@@ -73,6 +73,7 @@ CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int)
 IQ_CF32, IQ_CS16, IQ_CS8 = 0, 1, 2
 FIR_AUTO, FIR_FFT, FIR_MFMA, FIR_FUSED, FIR_WIDE = 0, 1, 2, 3, 4
 ERR_ARG, ERR_NO_DEVICE, ERR_TOO_LARGE, ERR_STATE = -1, -2, -3, -4   # include/atsc_hip.h
+MULTI_MAX_AHEAD = 8   # ATSC_HIP_MULTI_MAX_AHEAD
 
 _lib = None
 
@@ -122,6 +123,8 @@ def load_library():
     L.atsc_hip_iq_sample_bytes.argtypes = [C.c_int]
     L.atsc_hip_iq_sample_bytes.restype = C.c_size_t
     L.atsc_hip_process_chunked.argtypes = [vp, u8p, C.c_uint, C.c_size_t, CHUNK_CB, vp]
+    L.atsc_hip_process_multi.argtypes = [vp, C.c_int, u8p, C.c_uint, FIELD_CB, vp]
+    L.atsc_hip_multi_pending.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
     L.atsc_hip_error_string.argtypes = [C.c_int]
     L.atsc_hip_error_string.restype = C.c_char_p
     L.atsc_hip_version.restype = C.c_char_p
@@ -192,6 +195,27 @@ class Encoder:
         assert buf.size >= count * TS_PACKET_BYTES
         cb = FIELD_CB(lambda user, iq, nbytes: fn(iq, nbytes))
         check(self.L.atsc_hip_process(self.h, buf.ctypes.data, count, cb, None))
+
+    def process_multi(self, channel, pkts, count, fn):
+        """atsc_hip_process_multi: stream `channel` of a K-channel handle; fn(iq_ptr:int, nbytes:int) per completed field of
+        THAT stream, possibly during another stream's call (the wrapper keeps each stream's latest callback alive)."""
+        import numpy as np
+        buf = np.ascontiguousarray(np.frombuffer(pkts, dtype=np.uint8) if not isinstance(pkts, np.ndarray) else pkts)
+        assert buf.size >= count * TS_PACKET_BYTES
+        cb = FIELD_CB(lambda user, iq, nbytes: fn(iq, nbytes))
+        if not hasattr(self, "_multi_cbs"):
+            self._multi_cbs = {}
+        old = self._multi_cbs.get(channel)
+        self._multi_cbs[channel] = cb
+        try:
+            check(self.L.atsc_hip_process_multi(self.h, channel, buf.ctypes.data, count, cb, None))
+        finally:
+            del old   # released only after the call: the library may have fired it before taking the new one
+
+    def multi_pending(self, channel):
+        n = C.c_size_t(0)
+        check(self.L.atsc_hip_multi_pending(self.h, channel, C.byref(n)))
+        return n.value
 
     def process_chunked(self, pkts, count, mtu_samples, fn):
         """SDR-sink shape (util/atsc_encoder.cpp:84-100): fn(ptr:int, nsamples:int, fmt:int) per <= mtu piece of a field."""

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +61,14 @@ struct atsc_hip_encoder {
         hipEvent_t copied = nullptr;     // IQ of the slot's batch in h_iq (copy stream)
     } slot[2];
     hipStream_t compute_stream = nullptr, copy_stream = nullptr;
+    // multi-stream front (atsc_hip_process_multi): one FIFO and one callback per channel, two slots of channels x max_fields
+    struct Multi {
+        std::vector<std::vector<uint8_t>> fifo;      // per channel: TS bytes not yet encoded
+        std::vector<atsc_hip_field_cb> cb;           // per channel: the callback of its latest call
+        std::vector<void*> user;
+        Slot slot[2];
+        size_t slot_iq_bytes = 0;                    // what the slots' IQ buffers were sized for
+    } multi;
     hipStream_t last_stream = nullptr;   // the stream the handle's state was last touched on (batch calls, seek)
     hipEvent_t order_ev = nullptr;       // orders atsc_hip_process's private streams behind it
 
@@ -94,6 +103,13 @@ static int destroy_impl(atsc_hip_encoder* e) {
     hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
     hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc0); hipFree(e->d_osc_tab); hipFree(e->d_tables);
     for (auto& sl : e->slot) {
+        hipFree(sl.d_ts); hipFree(sl.d_iq);
+        if (sl.h_ts) hipHostFree(sl.h_ts);
+        if (sl.h_iq) hipHostFree(sl.h_iq);
+        if (sl.encoded) hipEventDestroy(sl.encoded);
+        if (sl.copied) hipEventDestroy(sl.copied);
+    }
+    for (auto& sl : e->multi.slot) {
         hipFree(sl.d_ts); hipFree(sl.d_iq);
         if (sl.h_ts) hipHostFree(sl.h_ts);
         if (sl.h_iq) hipHostFree(sl.h_iq);
@@ -593,6 +609,8 @@ static int process_impl(atsc_hip_encoder* e, const uint8_t* h_pkts, unsigned cou
                         atsc_hip_chunk_cb chunk_cb, size_t mtu_samples, void* user) {
     if (!e || (!h_pkts && count)) return ATSC_HIP_ERR_ARG;
     if (e->cfg.channels != 1 || e->pending_fields) return ATSC_HIP_ERR_STATE;
+    for (const auto& q : e->multi.fifo)
+        if (!q.empty()) return ATSC_HIP_ERR_STATE;   // the stream is being fed through atsc_hip_process_multi
     HIP_TRY(hipSetDevice(e->cfg.device));
     int rc = streaming_setup(e);
     if (rc) return rc;
@@ -667,6 +685,131 @@ extern "C" int atsc_hip_process_chunked(atsc_hip_encoder* e, const uint8_t* h_pk
                                         atsc_hip_chunk_cb cb, void* user) {
     if (!mtu_samples || !cb) return ATSC_HIP_ERR_ARG;
     return process_impl(e, h_pkts, count, nullptr, cb, mtu_samples, user);
+}
+
+// ---- multi-stream front: K independent TS streams on ONE K-channel handle (reference: one atsc_encoder per stream,
+// src/atsc/atsc.h:7-16, atsc.cpp:59-77; util/atsc_encoder.cpp:83-100).  Every stream keeps process()'s contract -- any packet
+// count, bytes copied before return, one callback per completed field, in order, on a calling thread -- but the fields of
+// all streams go through the GPU together, as batches of the many-channel kernels (the fused matrix-core form when the
+// channel count fills its groups), which is where the throughput of this library is.
+namespace {
+
+int multi_setup(atsc_hip_encoder* e) {
+    auto& m = e->multi;
+    const size_t K = e->cfg.channels, F = e->cfg.max_fields;
+    try {
+        if (m.fifo.size() != K) {
+            m.fifo.assign(K, {});
+            m.cb.assign(K, nullptr);
+            m.user.assign(K, nullptr);
+        }
+    } catch (const std::bad_alloc&) {
+        return static_cast<int>(hipErrorOutOfMemory);
+    }
+    if (!e->compute_stream) HIP_TRY(hipStreamCreateWithFlags(&e->compute_stream, hipStreamNonBlocking));
+    if (!e->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    // the IQ buffers follow the handle's current sample format and rate; they are rebuilt when a switch needs larger ones
+    const size_t iq_bytes = K * F * kFieldSyms * e->upsample * atsc_hip_iq_sample_bytes(e->iq_format);
+    for (auto& sl : m.slot) {
+        if (iq_bytes > m.slot_iq_bytes) {
+            if (sl.d_iq) { HIP_TRY(hipFree(sl.d_iq)); sl.d_iq = nullptr; }
+            if (sl.h_iq) { HIP_TRY(hipHostFree(sl.h_iq)); sl.h_iq = nullptr; }
+        }
+        if (!sl.d_ts) HIP_TRY(hipMalloc(&sl.d_ts, K * F * kFieldTs));
+        if (!sl.h_ts) HIP_TRY(hipHostMalloc(&sl.h_ts, K * F * kFieldTs, hipHostMallocDefault));
+        if (!sl.d_iq) HIP_TRY(hipMalloc(&sl.d_iq, iq_bytes));
+        if (!sl.h_iq) HIP_TRY(hipHostMalloc(&sl.h_iq, iq_bytes, hipHostMallocDefault));
+        if (!sl.encoded) HIP_TRY(hipEventCreateWithFlags(&sl.encoded, hipEventDisableTiming));
+        if (!sl.copied) HIP_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    }
+    if (iq_bytes > m.slot_iq_bytes) m.slot_iq_bytes = iq_bytes;
+    return ATSC_HIP_OK;
+}
+
+// Bytes handed to the GPU leave the FIFOs on every way out (normal return, HIP error, a callback that throws): those
+// fields have advanced the streams' state and must not be encoded again.
+struct MultiConsumedGuard {
+    atsc_hip_encoder* e;
+    size_t done = 0;   // bytes per channel
+    ~MultiConsumedGuard() {
+        if (e->compute_stream) hipStreamSynchronize(e->compute_stream);
+        if (e->copy_stream) hipStreamSynchronize(e->copy_stream);
+        if (done)
+            for (auto& q : e->multi.fifo) q.erase(q.begin(), q.begin() + done);
+    }
+};
+
+}  // namespace
+
+extern "C" int atsc_hip_process_multi(atsc_hip_encoder* e, int channel, const uint8_t* h_pkts, unsigned count,
+                                      atsc_hip_field_cb cb, void* user) {
+    if (!e || channel < 0 || channel >= e->cfg.channels || (!h_pkts && count)) return ATSC_HIP_ERR_ARG;
+    if (e->pending_fields || !e->pending.empty()) return ATSC_HIP_ERR_STATE;   // a batch in flight, or atsc_hip_process data buffered
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    int rc = multi_setup(e);
+    if (rc) return rc;
+    auto& m = e->multi;
+    const size_t K = e->cfg.channels, F = e->cfg.max_fields;
+    auto& mine = m.fifo[channel];
+    // a stream may run ahead of the slowest one by ATSC_HIP_MULTI_MAX_AHEAD batches, no further: the FIFOs are host memory
+    if (mine.size() + (size_t)count * ATSC_HIP_TS_PACKET_BYTES > ((size_t)ATSC_HIP_MULTI_MAX_AHEAD * F + 1) * kFieldTs)
+        return ATSC_HIP_ERR_TOO_LARGE;
+    try {
+        mine.insert(mine.end(), h_pkts, h_pkts + (size_t)count * ATSC_HIP_TS_PACKET_BYTES);   // copy-before-return (atsc.cpp:66)
+    } catch (const std::bad_alloc&) {
+        return static_cast<int>(hipErrorOutOfMemory);
+    }
+    m.cb[channel] = cb;
+    m.user[channel] = user;
+    size_t ready = SIZE_MAX;   // whole fields every stream has
+    for (const auto& q : m.fifo) ready = std::min(ready, q.size() / kFieldTs);
+    if (ready == 0) return ATSC_HIP_OK;
+
+    if (e->last_stream != e->compute_stream) {   // as in atsc_hip_process: behind whatever touched the handle's state last
+        if (!e->order_ev) HIP_TRY(hipEventCreateWithFlags(&e->order_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(e->order_ev, e->last_stream));
+        HIP_TRY(hipStreamWaitEvent(e->compute_stream, e->order_ev, 0));
+    }
+    const size_t ss = atsc_hip_iq_sample_bytes(e->iq_format);
+    const size_t field_bytes = (size_t)kFieldSyms * e->upsample * ss;
+    MultiConsumedGuard consumed{e};
+    int nf_of[2] = {0, 0};
+    auto submit = [&](unsigned k) -> int {
+        auto& sl = m.slot[k & 1];
+        const int nf = (int)std::min<size_t>(ready - consumed.done / kFieldTs, F);
+        nf_of[k & 1] = nf;
+        if (nf == 0) return ATSC_HIP_OK;
+        for (size_t c = 0; c < K; ++c)   // [channel][field][312 x 188], packed with this batch's field count
+            std::memcpy(sl.h_ts + c * nf * kFieldTs, m.fifo[c].data() + consumed.done, (size_t)nf * kFieldTs);
+        HIP_TRY(hipMemcpyAsync(sl.d_ts, sl.h_ts, K * nf * kFieldTs, hipMemcpyHostToDevice, e->compute_stream));
+        consumed.done += (size_t)nf * kFieldTs;
+        const int r = atsc_hip_encode_batch(e, sl.d_ts, nf, nullptr, sl.d_iq, e->compute_stream);
+        if (r) return r;
+        HIP_TRY(hipEventRecord(sl.encoded, e->compute_stream));
+        HIP_TRY(hipStreamWaitEvent(e->copy_stream, sl.encoded, 0));
+        HIP_TRY(hipMemcpyAsync(sl.h_iq, sl.d_iq, K * nf * field_bytes, hipMemcpyDeviceToHost, e->copy_stream));
+        HIP_TRY(hipEventRecord(sl.copied, e->copy_stream));
+        return ATSC_HIP_OK;
+    };
+    rc = submit(0);
+    if (rc) return rc;
+    for (unsigned k = 0; nf_of[k & 1] > 0; ++k) {
+        rc = submit(k + 1);   // upload + kernels of the next batch overlap this one's download and callbacks
+        if (rc) return rc;
+        auto& sl = m.slot[k & 1];
+        HIP_TRY(hipEventSynchronize(sl.copied));
+        const int nf = nf_of[k & 1];
+        for (int f = 0; f < nf; ++f)        // field-major: the streams move on together
+            for (size_t c = 0; c < K; ++c)
+                if (m.cb[c]) m.cb[c](m.user[c], sl.h_iq + (c * nf + f) * field_bytes, (unsigned)field_bytes);
+    }
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_multi_pending(atsc_hip_encoder* e, int channel, size_t* packets) {
+    if (!e || !packets || channel < 0 || channel >= e->cfg.channels) return ATSC_HIP_ERR_ARG;
+    *packets = (size_t)channel < e->multi.fifo.size() ? e->multi.fifo[channel].size() / ATSC_HIP_TS_PACKET_BYTES : 0;
+    return ATSC_HIP_OK;
 }
 
 extern "C" int atsc_hip_export_state(atsc_hip_encoder* e, int channel, atsc_hip_stream_state* out) {

@@ -187,6 +187,30 @@ int atsc_hip_get_fir_form(atsc_hip_encoder* enc);
 int atsc_hip_set_upsample(atsc_hip_encoder* enc, int factor); /* 1 (default) or 2 */
 int atsc_hip_get_upsample(atsc_hip_encoder* enc);
 
+/* K streams through the reference's process() contract on ONE K-channel handle.  Replaces K instances of
+ * atsc::atsc_encoder (src/atsc/atsc.h:7-16, one per TS as in util/atsc_encoder.cpp:83-100), each with its own
+ * process(pkt, count, fn) (src/atsc/atsc.cpp:59-77): `channel` says which stream the packets belong to.  The packets are
+ * copied before the call returns and (cb, user) is remembered as THAT stream's callback.  Whenever every stream of the
+ * handle has at least one whole field buffered, the call that completes the set runs the fields all streams have
+ * (batches of up to max_fields, two slots: upload + kernels of batch k+1 overlap the download and callbacks of batch k)
+ * through atsc_hip_encode_batch -- the many-channel kernels, the fused matrix-core form when the channel count fills its
+ * groups (atsc_hip_get_fir_form) -- and fires every stream's callback for its fields: in field order per stream,
+ * field-major across streams, synchronously on the thread of THIS call, before it returns.  So a stream's callback may
+ * run inside another stream's call; it must stay callable until the handle is destroyed or the stream's next call
+ * replaces it.  Nothing stays in flight between calls; a trailing partial field stays buffered.
+ * The streams advance in lockstep (one field index for the handle): a stream that ends starves the others -- keep feeding
+ * it null packets, as a multiplexer does.  A stream may be ahead of the slowest one by at most
+ * ATSC_HIP_MULTI_MAX_AHEAD x max_fields fields (ATSC_HIP_ERR_TOO_LARGE beyond; nothing is copied then).
+ * Not thread-safe, like the reference (one thread at a time per handle).  Cannot be mixed with atsc_hip_process on the
+ * same handle while either has bytes buffered (ATSC_HIP_ERR_STATE).  Errors as for atsc_hip_process.
+ * Host memory: 2 x channels x max_fields x (58656 + 260416 x sample bytes x upsample) pinned bytes, allocated on first use. */
+#define ATSC_HIP_MULTI_MAX_AHEAD 8
+int atsc_hip_process_multi(atsc_hip_encoder* enc, int channel, const uint8_t* h_pkts, unsigned count, atsc_hip_field_cb cb,
+                           void* user);
+/* TS packets of `channel` buffered by atsc_hip_process_multi and not yet encoded.  No reference counterpart (the
+ * reference's field buffer is private, src/atsc/atsc.cpp:61-70); for callers that pace the streams. */
+int atsc_hip_multi_pending(atsc_hip_encoder* enc, int channel, size_t* packets);
+
 /* atsc_hip_process with the radio-side chunking of the reference's transmitter loop (util/atsc_encoder.cpp:84-100:
  * `transfer = min(remaining, MTU)` per writeStream call, chunks never span a field): cb(user, samples, n, format)
  * for every piece of at most mtu_samples samples of every completed field, synchronously and in order. */
