@@ -40,61 +40,110 @@ constexpr int kRsThreads = 1024;
 
 typedef uint32_t u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-__global__ __launch_bounds__(kRsThreads) void k_rs_parity(const uint8_t* __restrict__ ts, const uint4* __restrict__ rs_lds,
-                                                          const uint4* __restrict__ prbs_parity,
-                                                          uint4* __restrict__ parity, long npackets) {
-    constexpr int kCopies = 8;              // of the 16-byte parts: 8 x 16 KB + 32 KB below = all of the CU's 160 KB (4 copies: +8 %)
-    __shared__ uint4 s_a[4 * 256 * kCopies];
-    __shared__ uint32_t s_e[4 * 256 * 8];   // 32768 B
+// PPL: packets per lane, worked on side by side.  The product runs PPL = 1; two independent lookup chains per lane (512
+// threads, 169 VGPRs) were measured and lose: 0.103 against 0.091 ms.
+template <int PPL>
+__global__ __launch_bounds__(kRsThreads / PPL) void k_rs_parity(const uint8_t* __restrict__ ts, const uint4* __restrict__ rs_lds,
+                                                                const uint4* __restrict__ prbs_parity,
+                                                                uint4* __restrict__ parity, long npackets) {
+    constexpr int kThreads = kRsThreads / PPL;
+    // The tables in LDS, laid out so that NO lookup conflicts (round 3).  A dword of TS takes four lookups, one per table
+    // T1..T4, each a 16-byte part and a 4-byte part of a 20-byte row; the rows are random, so a ds_read_b128 (16 lanes per
+    // LDS cycle) is conflict-free only if the 16 lanes of a service group can never meet in a 16-byte slot, and a
+    // ds_read_b32 only if the lanes of a half-wave can never meet in a bank.  A copy of a table per lane of a service group
+    // would do it (16 x 16 KB: too much); instead the ORDER of a lane's four lookups is rotated by lane: in lookup slot i,
+    // lane group g = (lane >> 2) & 3 reads table (g + i) & 3, so the 16 lanes of a service group read four DIFFERENT tables,
+    // four lanes each, and four copies per table (copy = lane & 3) give every lane its own slot: row r of table m, copy c at
+    // byte r * 256 + 64 m + 16 c -- 64 KB.  The 4-byte parts the same way with 16 copies (lane bits 0, 1, 4, 5): bank
+    // 16 m + 4 c + k, all 64 lanes apart -- another 64 KB.  XOR is commutative, so the order of the lookups is free.
+    // An address is ONE v_perm_b32: byte (3 - m) of u into bits 8..15 over a per-lane base.
+    __shared__ uint4 s_tab[8192];            // [A: 256 rows x 16 slots x 16 B | E: 256 rows x 64 banks x 4 B] = 128 KB
     const int tid = threadIdx.x;
+    {
+        const uint32_t* e_src = reinterpret_cast<const uint32_t*>(rs_lds) + 16384;   // host image: dword (m*256 + v)*8 (tables.cpp)
 #pragma unroll
-    for (int i = 0; i < 4 * kCopies / 4; ++i) {
-        const int idx = tid + kRsThreads * i;
-        s_a[idx] = rs_lds[(idx / kCopies) * 4 + (idx & 3)];     // (the host image holds four copies per row)
+        for (int it = 0; it < 4 * PPL; ++it) {
+            const int j = tid + kThreads * it;
+            const int r = j >> 4, m = (j >> 2) & 3;
+            s_tab[j] = rs_lds[(m * 256 + r) * 4];
+            const uint32_t e = e_src[(m * 256 + r) * 8];
+            s_tab[4096 + j] = make_uint4(e, e, e, e);
+        }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) reinterpret_cast<uint4*>(s_e)[tid + kRsThreads * i] = rs_lds[4096 + tid + kRsThreads * i];
     __syncthreads();
 
-    const uint4* ta = s_a + (tid & (kCopies - 1));
-    const uint32_t* te = s_e + (tid & 7);
-    for (long P = (long)blockIdx.x * kRsThreads + tid; P < npackets; P += (long)gridDim.x * kRsThreads) {
-        uint32_t d[48];
-        {
-            const u32x4a4* src = reinterpret_cast<const u32x4a4*>(ts + P * kTsBytes);
+    const int lane = tid & 63;
+    const uint32_t c4 = lane & 3, g = (lane >> 2) & 3, k4 = (lane >> 4) & 3;
+    uint32_t sel[4], base_a[4], base_e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t m = (g + i) & 3;
+        // table index m = 3 is T4 = the first byte in time = the lowest byte of the dword: table m takes byte 3 - m
+        sel[i] = 0x0c020000u | ((4u + (3u - m)) << 8);          // {0, base byte 2, u byte (3 - m), base byte 0}
+        base_a[i] = 64u * m + 16u * c4;
+        base_e[i] = 0x10000u + 64u * m + 16u * c4 + 4u * k4;
+    }
+    const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_tab);
+    // A block takes kRsThreads consecutive packets per trip (lane's packets are kThreads apart).  (Loading the next trip's
+    // dwords into the registers of this trip as they fall free -- no bubble at the top of a trip, no extra registers -- was
+    // measured and loses: 0.107 against 0.091 ms; the loads then sit between the lookups of every fourth step.)
+    for (long P0 = (long)blockIdx.x * kRsThreads + tid; P0 < npackets; P0 += (long)gridDim.x * kRsThreads) {
+        uint32_t d[PPL][48];
+        bool ok[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const long P = P0 + (long)q * kThreads;
+            ok[q] = P < npackets;
+            const uint8_t* pk = ts + (ok[q] ? P : P0) * kTsBytes;
+            const u32x4a4* src = reinterpret_cast<const u32x4a4*>(pk);
 #pragma unroll
             for (int i = 0; i < 11; ++i) {
                 const u32x4a4 v = src[i];
-                d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+                d[q][4 * i] = v.x; d[q][4 * i + 1] = v.y; d[q][4 * i + 2] = v.z; d[q][4 * i + 3] = v.w;
             }
-            const uint32_t* tail = reinterpret_cast<const uint32_t*>(ts + P * kTsBytes) + 44;
-            d[44] = tail[0]; d[45] = tail[1]; d[46] = tail[2];
+            const uint32_t* tail = reinterpret_cast<const uint32_t*>(pk) + 44;
+            d[q][44] = tail[0]; d[q][45] = tail[1]; d[q][46] = tail[2];
+            d[q][0] &= 0xffffff00u;  // TS sync byte: dropped unchecked (randomize.h:48)
         }
-        d[0] &= 0xffffff00u;  // TS sync byte: dropped unchecked (randomize.h:48)
-        uint32_t b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
+        uint32_t b0[PPL], b1[PPL], b2[PPL], b3[PPL], b4[PPL];
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) b0[q] = b1[q] = b2[q] = b3[q] = b4[q] = 0;
 #pragma unroll
         for (int w = 0; w < 47; ++w) {
-            const uint32_t u = d[w] ^ b0;
-            // first byte in time = lowest byte = four steps from the end -> table T4 (index 3)
-            const uint32_t i4 = 3 * 256 + (u & 0xffu), i3 = 2 * 256 + ((u >> 8) & 0xffu), i2 = 256 + ((u >> 16) & 0xffu),
-                           i1 = u >> 24;
-            const uint4 r4 = ta[i4 * kCopies], r3 = ta[i3 * kCopies], r2 = ta[i2 * kCopies], r1 = ta[i1 * kCopies];
-            const uint32_t e = te[i4 * 8] ^ te[i3 * 8] ^ te[i2 * 8] ^ te[i1 * 8];
-            b0 = b1 ^ r4.x ^ r3.x ^ r2.x ^ r1.x;
-            b1 = b2 ^ r4.y ^ r3.y ^ r2.y ^ r1.y;
-            b2 = b3 ^ r4.z ^ r3.z ^ r2.z ^ r1.z;
-            b3 = b4 ^ r4.w ^ r3.w ^ r2.w ^ r1.w;
-            b4 = e;
+            uint4 r[PPL][4];
+            uint32_t e[PPL][4];
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const uint32_t u = d[q][w] ^ b0[q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r[q][i] = *reinterpret_cast<const uint4*>(lds + __builtin_amdgcn_perm(u, base_a[i], sel[i]));
+                    e[q][i] = *reinterpret_cast<const uint32_t*>(lds + __builtin_amdgcn_perm(u, base_e[i], sel[i]));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                b0[q] = b1[q] ^ r[q][0].x ^ r[q][1].x ^ r[q][2].x ^ r[q][3].x;
+                b1[q] = b2[q] ^ r[q][0].y ^ r[q][1].y ^ r[q][2].y ^ r[q][3].y;
+                b2[q] = b3[q] ^ r[q][0].z ^ r[q][1].z ^ r[q][2].z ^ r[q][3].z;
+                b3[q] = b4[q] ^ r[q][0].w ^ r[q][1].w ^ r[q][2].w ^ r[q][3].w;
+                b4[q] = e[q][0] ^ e[q][1] ^ e[q][2] ^ e[q][3];
+            }
         }
-        const int s = (int)(P % kPackets);
-        const uint4 pa = prbs_parity[2 * s];
-        const uint32_t pe = reinterpret_cast<const uint32_t*>(prbs_parity)[8 * s + 4];
-        // The record is shifted by three bytes (parity byte j at byte 3 + j): the interleaver keeps a packet's 207 coded
-        // bytes dword-aligned in LDS, where the first parity byte is the top byte of the dword that holds data bytes 184..186
-        const uint32_t p0 = b0 ^ pa.x, p1 = b1 ^ pa.y, p2 = b2 ^ pa.z, p3 = b3 ^ pa.w, p4 = b4 ^ pe;
-        parity[2 * P] = make_uint4(p0 << 24, __builtin_amdgcn_alignbyte(p1, p0, 1), __builtin_amdgcn_alignbyte(p2, p1, 1),
-                                   __builtin_amdgcn_alignbyte(p3, p2, 1));
-        reinterpret_cast<uint2*>(parity)[4 * P + 2] = make_uint2(__builtin_amdgcn_alignbyte(p4, p3, 1), p4 >> 8);
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const long P = P0 + (long)q * kThreads;
+            if (!ok[q]) continue;
+            const int s = (int)(P % kPackets);
+            const uint4 pa = prbs_parity[2 * s];
+            const uint32_t pe = reinterpret_cast<const uint32_t*>(prbs_parity)[8 * s + 4];
+            // The record is shifted by three bytes (parity byte j at byte 3 + j): the interleaver keeps a packet's 207 coded
+            // bytes dword-aligned in LDS, where the first parity byte is the top byte of the dword that holds data bytes 184..186
+            const uint32_t p0 = b0[q] ^ pa.x, p1 = b1[q] ^ pa.y, p2 = b2[q] ^ pa.z, p3 = b3[q] ^ pa.w, p4 = b4[q] ^ pe;
+            parity[2 * P] = make_uint4(p0 << 24, __builtin_amdgcn_alignbyte(p1, p0, 1), __builtin_amdgcn_alignbyte(p2, p1, 1),
+                                       __builtin_amdgcn_alignbyte(p3, p2, 1));
+            reinterpret_cast<uint2*>(parity)[4 * P + 2] = make_uint2(__builtin_amdgcn_alignbyte(p4, p3, 1), p4 >> 8);
+        }
     }
 }
 
@@ -179,8 +228,18 @@ void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, s
     (void)ts_stride;
     const long npackets = (long)channels * fields * kPackets;
     const long want = (npackets + kRsThreads - 1) / kRsThreads;
-    const unsigned grid = (unsigned)(want < 1024 ? want : 1024);  // grid-stride: the 96 KB table image loads once per block
-    hipLaunchKernelGGL(k_rs_parity, dim3(grid), dim3(kRsThreads), 0, s, d_ts, t.rs_lds, t.prbs_parity, b.parity, npackets);
+    // One workgroup per CU, grid-stride: the 128 KB table image is built once per CU (1024 workgroups, four rounds of table
+    // builds: 0.102 ms; 512: 0.096; 256: 0.091, same box)
+    static int cus_of[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && cus_of[dev] == 0) {
+        int n = 0;
+        cus_of[dev] = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0 ? n : 256;
+    }
+    const long cap = dev >= 0 && dev < 64 ? cus_of[dev] : 256;
+    const unsigned grid = (unsigned)(want < cap ? want : cap);
+    hipLaunchKernelGGL(k_rs_parity<1>, dim3(grid), dim3(kRsThreads), 0, s, d_ts, t.rs_lds, t.prbs_parity, b.parity, npackets);
 }
 
 void launch_assemble(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
