@@ -54,8 +54,11 @@ __global__ __launch_bounds__(kRsThreads / PPL) void k_rs_parity(const uint8_t* _
     // would do it (16 x 16 KB: too much); instead the ORDER of a lane's four lookups is rotated by lane: in lookup slot i,
     // lane group g = (lane >> 2) & 3 reads table (g + i) & 3, so the 16 lanes of a service group read four DIFFERENT tables,
     // four lanes each, and four copies per table (copy = lane & 3) give every lane its own slot: row r of table m, copy c at
-    // byte r * 256 + 64 m + 16 c -- 64 KB.  The 4-byte parts the same way with 16 copies (lane bits 0, 1, 4, 5): bank
-    // 16 m + 4 c + k, all 64 lanes apart -- another 64 KB.  XOR is commutative, so the order of the lookups is free.
+    // byte r * 256 + 64 m + 16 c -- 64 KB (the service groups of ds_read_b128 are lanes {0-3, 12-15, 20-27}, {4-11, 16-19,
+    // 28-31}, ... : each holds every (lane group, copy) pair once).  The 4-byte parts the same way: a ds_read_b32 serves lanes
+    // 0-31 and 32-63 in one LDS cycle each over 32 banks, so a half-wave needs 32 different banks: dword 8 m + 2 c + (lane bit
+    // 4) of the row's first 32 dwords for lanes 0-31, the same + 32 for lanes 32-63 -- another 64 KB.  XOR is commutative, so
+    // the order of the lookups is free.
     // An address is ONE v_perm_b32: byte (3 - m) of u into bits 8..15 over a per-lane base.
     __shared__ uint4 s_tab[8192];            // [A: 256 rows x 16 slots x 16 B | E: 256 rows x 64 banks x 4 B] = 128 KB
     const int tid = threadIdx.x;
@@ -64,9 +67,9 @@ __global__ __launch_bounds__(kRsThreads / PPL) void k_rs_parity(const uint8_t* _
 #pragma unroll
         for (int it = 0; it < 4 * PPL; ++it) {
             const int j = tid + kThreads * it;
-            const int r = j >> 4, m = (j >> 2) & 3;
+            const int r = j >> 4, m = (j >> 2) & 3, me = (j >> 1) & 3;   // 16-byte slot j & 15: table of the A part / of the E dwords
             s_tab[j] = rs_lds[(m * 256 + r) * 4];
-            const uint32_t e = e_src[(m * 256 + r) * 8];
+            const uint32_t e = e_src[(me * 256 + r) * 8];
             s_tab[4096 + j] = make_uint4(e, e, e, e);
         }
     }
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(kRsThreads / PPL) void k_rs_parity(const uint8_t* _
         // table index m = 3 is T4 = the first byte in time = the lowest byte of the dword: table m takes byte 3 - m
         sel[i] = 0x0c020000u | ((4u + (3u - m)) << 8);          // {0, base byte 2, u byte (3 - m), base byte 0}
         base_a[i] = 64u * m + 16u * c4;
-        base_e[i] = 0x10000u + 64u * m + 16u * c4 + 4u * k4;
+        base_e[i] = 0x10000u + 4u * (8u * m + 2u * c4 + (k4 & 1u) + 32u * (k4 >> 1));
     }
     const uint8_t* lds = reinterpret_cast<const uint8_t*>(s_tab);
     // A block takes kRsThreads consecutive packets per trip (lane's packets are kThreads apart).  (Loading the next trip's
