@@ -42,13 +42,11 @@ SYMBOL_RATE_MSPS = 4500000.0 / 286 * 684 / 1e6  # 10.762238 Msym/s = one real-ti
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
 CHAIN_BYTES_PER_SYM = 8.225    # whole chain fused minimum (58656 B in + 2083328 B out per field)
 FIELD_SYMBOLS = 313 * 832
-FUSED_DTYPE = ("f32 (oscillator recursion and accumulation in fp32; the mixer product and the FIR's multiplies run on two "
-               "fp16 pieces of each fp32 operand, matrix cores; the low-order pieces are left out for the outermost taps: "
-               "1.7e-6 of full scale measured, 7.2e-6 worst case over every input with every error term at its bound "
-               "(scripts/fir_error_budget.py), tolerance 1e-5)")
-WIDE_DTYPE = ("f32 (oscillator recursion and accumulation in fp32; the tap x oscillator operand is formed per tile in two fp16 pieces, "
-              "the levels are exact in one, matrix cores; the low-order piece is left out for the two outermost K-steps: 1.2e-6 of "
-              "full scale measured, 8.4e-6 worst case with every error term at its bound, tolerance 1e-5)")
+# (the line the driver keeps is its stdout TAIL: every string below is kept short so that the whole line stays under 4 KB)
+FUSED_DTYPE = ("f32 (fp32 oscillator and accumulation; products on two fp16 pieces per operand, matrix cores, low-order pieces "
+               "left out of the outermost taps: <=1.7e-6 measured, 7.2e-6 worst case with every term at its bound, tolerance 1e-5)")
+WIDE_DTYPE = ("f32 (fp32 oscillator and accumulation; tap x oscillator operand in two fp16 pieces per tile, levels exact in one, "
+              "matrix cores: 1.2e-6 measured, 8.4e-6 worst case with every term at its bound, tolerance 1e-5)")
 METRIC = "real-time ATSC channels per GPU (Msym/s; 10.76=1 ch) at 1/2/4/8 MI355X"
 PROFILE_ROUND = "r03"
 PROFILE_DIR = os.path.join(ROOT, "profiles", PROFILE_ROUND)
@@ -133,8 +131,7 @@ def cpu_baseline(sample_fields=400):
             "cores_from": why, "cpus_visible": os.cpu_count(),
             "single_thread_msym_s": round(single, 2),
             "channels_equiv": round(multi / SYMBOL_RATE_MSPS, 2),
-            "sample": f"{sample_fields}-field null-packet TS per thread, in memory, null sink, "
-                      f"{ncores} threads = every core this process may use (one encoder each) + 1-thread run"}
+            "sample": f"{sample_fields} fields of null packets per thread, null sink, {ncores} threads (one encoder each) + a 1-thread run"}
 
 
 def parse_args(argv=None):
@@ -163,6 +160,7 @@ def parse_args(argv=None):
                          "out of the same pass, the even ones the reference's.  Not the headline configuration")
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the headline loop: this many seconds of back-to-back steps, reported as `sustained` (0 = skip)")
+    ap.add_argument("--verbose-line", action="store_true", help="keep the replayed counter summaries in the line (long)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs behind the headline loop (sustained run, fp32-form run, in-run IQ error): profiler passes")
     ap.add_argument("--rccl", action="store_true",
@@ -267,9 +265,27 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+LINE_LIMIT = 3900   # the driver keeps the TAIL of stdout: a line longer than its window would lose its head (metric, value)
+
+
 def emit(json_fd, out):
+    """ONE line.  If it outgrows LINE_LIMIT the explanatory keys go first (notes, then the replayed-profile pointers, then the
+    secondary stage objects); the contract keys and the measured numbers stay."""
+    def drop_notes(o):
+        if isinstance(o, dict):
+            return {k: drop_notes(v) for k, v in o.items() if k not in ("note", "sample", "measured", "handoff_note")}
+        return o
+    line = json.dumps(out)
+    for shrink in (drop_notes,
+                   lambda o: {k: v for k, v in o.items() if k != "roofline_other_stages"},
+                   lambda o: {k: v for k, v in o.items() if k not in ("fp32_form", "rank_devices")}):
+        if len(line) <= LINE_LIMIT:
+            break
+        out = shrink(out)
+        out["line_shortened"] = True
+        line = json.dumps(out)
     sys.stdout.flush()
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.write(json_fd, (line + "\n").encode())
 
 
 def run_stub(args, json_fd):
@@ -377,25 +393,23 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world,
     replayed = {"dir": f"profiles/{PROFILE_ROUND}", "kernel_sources_changed_since_profile": kernel_sources_changed_since_profile()}
     util = load_profile_json("utilisation.json")
     if util and util.get("workload") == f"{C_} channels x {F} fields":
-        replayed["utilisation"] = {"commit": util.get("commit"), "kernels": util.get("kernels", {})}
+        replayed["commit"] = util.get("commit")
+        if args.verbose_line:   # the counter summaries themselves stay in the committed files (utilisation.json, stall_counters.md)
+            replayed["utilisation"] = util.get("kernels", {})
 
     traffic, traffic_src = None, None
     tj = load_profile_json("traffic.json")
     if tj and tj.get("workload") == f"{C_} channels x {F} fields" and sample_bytes == 8 and up == 1 and \
             ("fused" in tj.get("kernel", "")) == fused:
         traffic = tj["traffic_bytes_per_launch"]
-        traffic_src = {"file": f"profiles/{PROFILE_ROUND}/traffic.json", "commit": tj.get("commit"), "kernel": tj.get("kernel"),
+        traffic_src = {"file": f"profiles/{PROFILE_ROUND}/traffic.json", "commit": tj.get("commit"),
                        "kernel_sources_changed_since_profile": replayed["kernel_sources_changed_since_profile"],
-                       "note": "PMC passes of scripts/profile_gpu.sh (fetch, write) on the named commit, summarised by scripts/summarize_profile.py; not re-measured in this run"}
+                       "note": "replayed from the committed FETCH_SIZE / WRITE_SIZE passes, not re-measured in this run"}
     stages["_from_committed_profile"] = replayed
     roofline = {
-        "kernel": ("k_mix_fir_w (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes; FIR as Y = W.X on the "
-                   "matrix cores with W = taps x oscillator formed per tile in two fp16 pieces and shared by 64 channels, levels exact "
-                   "in one fp16 piece)" if wide else
-                   "k_mix_fir_mm<cf32, fused> (precoder / trellis / mapper / syncs regenerated in LDS from the interleaved bytes, "
-                   "pilot + offset mixer first, then the 112-tap RRC FIR as Y = A.Z with a constant Toeplitz tap operand on the "
-                   "matrix cores, fp16 hi/lo split of both operands)" if fused else
-                   "k_mix_fir_fft (pilot/offset mixer + 112-tap RRC FIR, overlap-save 1024-point FFT form)"),
+        "kernel": ("k_mix_fir_w (trellis / map / sync + mixer + RRC FIR, oscillator folded into the tap operand)" if wide else
+                   "k_mix_fir_mm<fused> (trellis / map / sync + mixer + RRC FIR as a banded GEMM on the matrix cores)" if fused else
+                   "k_mix_fir_fft (mixer + RRC FIR, overlap-save FFT form)"),
         "bound": "hbm",
         "achieved": round(fir_gbs, 1),
         "peak": HBM_PEAK_GBS,
@@ -405,10 +419,9 @@ def stage_report(args, atsc_amd, enc, C_, F, fused, sample_bytes, msym_s, world,
         "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": fir_bytes_per_sym * sym_per_step_gpu,
         "avg_launch_ms": round(stage_ms["mix_fir"], 4),
-        "note": f"algorithmic bytes = {fir_bytes_per_sym:.3f} B/symbol ("
+        "note": f"{fir_bytes_per_sym:.3f} B/symbol algorithmic ("
                 + ("0.248 B interleaved bytes in" if fused else "1 B symbol in")
-                + f" + {up} x {sample_bytes} B {args.iq_format} out, SURVEY 8d); peak = the 8 TB/s spec figure (a pure store "
-                "stream of this shape reaches 5.7 TB/s on this part, DESIGN.md)",
+                + f" + {up} x {sample_bytes} B {args.iq_format} out, SURVEY 8d); peak = 8 TB/s spec",
         "whole_chain_gbs": round((CHAIN_BYTES_PER_SYM - 8 + sample_bytes * up) * msym_s * 1e6 / world / 1e9, 1),
     }
     return stage_ms, roofline, stages
@@ -429,10 +442,9 @@ def iq_error_in_run(ts, first_iq, F):
         e = float(np.abs(got - np.asarray(want, dtype=np.float32).reshape(-1)).max())
         per[str(c)] = e
         worst = max(worst, e)
-    return {"max_abs_error": worst, "per_channel": per, "fields": F, "full_scale": 1.0, "tolerance": 1e-5,
-            "against": "oracle/_ref (the compiled reference)" if use_ref else "oracle/ (C restatement)",
-            "measured": "in this run: the handle's first batch, before the warm-up",
-            "checker_seconds": round(time.perf_counter() - t0, 2)}
+    return {"max_abs_error": worst, "channels": sorted(int(c) for c in per), "fields": F, "tolerance": 1e-5,
+            "against": "oracle/_ref (compiled reference)" if use_ref else "oracle/ (C restatement)",
+            "measured": "in this run, first batch", "checker_seconds": round(time.perf_counter() - t0, 2)}
 
 
 def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
@@ -519,7 +531,7 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
             dt = time.perf_counter() - t1
             sustained = {"steps": n, "seconds": round(dt, 3), "ms_per_step": round(dt / n * 1e3, 4),
                          "value": round(sym_per_step_gpu * n / dt / 1e6, 2), "unit": "Msym/s (this GPU)",
-                         "note": "back-to-back steps right after the headline loop, same handle and buffers"}
+                         "note": "back-to-back steps right behind the timed loop"}
         if fused and up == 1:
             # the same shard at the reference's arithmetic: fp32 throughout (k_trellis_map + k_mix_fir_fft)
             e32 = atsc_amd.Encoder(channels=C_, max_fields=F, device=rk.local_rank, timing=True)
@@ -542,13 +554,13 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
                     st32[k] += tm[k] / n32
             fir32 = st32["mix_fir"] / 1e3
             gbs32 = (1.0 + iq_bytes) * sym_per_step_gpu / fir32 / 1e9
-            fp32_form = {"fir_form": "fft (fp32 throughout: k_trellis_map writes u8 symbols, k_mix_fir_fft reads them)",
+            fp32_form = {"fir_form": "fft + k_trellis_map (fp32 throughout)",
                          "steps": n32, "ms_per_step": round(dt / n32 * 1e3, 4),
                          "value": round(sym_per_step_gpu * n32 / dt / 1e6, 2), "unit": "Msym/s (this GPU)",
-                         "stage_ms": {k: round(v, 4) for k, v in st32.items()},
+                         "stage_ms": {k: round(st32[k], 4) for k in ("trellis_map", "mix_fir")},
                          "roofline": {"kernel": "k_mix_fir_fft", "bound": "hbm", "achieved": round(gbs32, 1), "peak": HBM_PEAK_GBS,
                                       "unit": "GB/s", "frac": round(gbs32 / HBM_PEAK_GBS, 4),
-                                      "note": f"1 B u8 symbol in + {iq_bytes} B out per symbol; the step also pays k_trellis_map"}}
+                                      "note": f"1 B symbol in + {iq_bytes} B out per symbol"}}
             del e32
     if first_iq is not None:
         try:
