@@ -37,7 +37,7 @@ EXPORTS = ("atsc_hip_create", "atsc_hip_destroy", "atsc_hip_process", "atsc_hip_
            "atsc_hip_encode_begin", "atsc_hip_encode_finish",
            "atsc_hip_encode_batch_host", "atsc_hip_mix_fir", "atsc_hip_mix_fir_static", "atsc_hip_export_state", "atsc_hip_import_state", "atsc_hip_seek",
            "atsc_hip_span_parity", "atsc_hip_stage_buffer", "atsc_hip_last_timings", "atsc_hip_timing_reserve",
-           "atsc_hip_batch_timings", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form", "atsc_hip_set_upsample", "atsc_hip_get_upsample",
+           "atsc_hip_batch_timings", "atsc_hip_timing_select", "atsc_hip_get_table", "atsc_hip_set_iq_format", "atsc_hip_iq_sample_bytes", "atsc_hip_set_fir_form", "atsc_hip_get_fir_form", "atsc_hip_set_upsample", "atsc_hip_get_upsample",
            "atsc_hip_process_chunked", "atsc_hip_process_multi", "atsc_hip_multi_pending",
            "atsc_hip_error_string", "atsc_hip_version",
            # include/atsc_hip_resample.h
@@ -125,6 +125,7 @@ def load_library():
     L.atsc_hip_process_chunked.argtypes = [vp, u8p, C.c_uint, C.c_size_t, CHUNK_CB, vp]
     L.atsc_hip_process_multi.argtypes = [vp, C.c_int, u8p, C.c_uint, FIELD_CB, vp]
     L.atsc_hip_multi_pending.argtypes = [vp, C.c_int, C.POINTER(C.c_size_t)]
+    L.atsc_hip_timing_select.argtypes = [vp, C.c_uint]
     L.atsc_hip_error_string.argtypes = [C.c_int]
     L.atsc_hip_error_string.restype = C.c_char_p
     L.atsc_hip_version.restype = C.c_char_p
@@ -299,6 +300,11 @@ class Encoder:
 
     def timing_reserve(self, nslots):
         check(self.L.atsc_hip_timing_reserve(self.h, nslots))
+
+    def timing_select(self, stages=None):
+        """atsc_hip_timing_select: time only the named stages (None: all)."""
+        mask = 0xFFFFFFFF if stages is None else sum(1 << STAGE_NAMES.index(k) for k in stages)
+        check(self.L.atsc_hip_timing_select(self.h, mask))
 
     def batch_timings(self, batch):
         ms = (C.c_float * NSTAGES)()

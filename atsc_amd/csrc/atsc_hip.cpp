@@ -79,6 +79,7 @@ struct atsc_hip_encoder {
     };
     std::vector<EventSet> slots;
     bool ev_valid = false;
+    unsigned mark_mask = ~0u;   // which marks a batch records (atsc_hip_timing_select)
     size_t batches = 0;         // batches launched since the last timing reset
     EventSet* cur = nullptr;
 };
@@ -100,7 +101,8 @@ static int destroy_impl(atsc_hip_encoder* e) {
     if (!e) return 0;
     hipSetDevice(e->cfg.device);
     hipFree(e->buf.coded); hipFree(e->buf.tail); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
-    hipFree(e->buf.carry); hipFree(e->buf.span_par); hipFree(e->buf.last_group);
+    hipFree(e->buf.carry); hipFree(e->buf.span_par);
+    hipFree(std::min(e->buf.last_group, e->buf.last_group_next));   // one allocation, two halves that swap roles
     hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc0); hipFree(e->d_osc_tab); hipFree(e->d_tables);
     for (auto& sl : e->slot) {
         hipFree(sl.d_ts); hipFree(sl.d_iq);
@@ -212,14 +214,15 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     TRY_OR_FREE(hipMalloc(&e->buf.cin, C * F * kParts * sizeof(uint4)));
     TRY_OR_FREE(hipMalloc(&e->buf.carry, C * sizeof(uint4)));
     TRY_OR_FREE(hipMalloc(&e->buf.span_par, C * sizeof(uint4)));
-    TRY_OR_FREE(hipMalloc(&e->buf.last_group, C * 16));
+    TRY_OR_FREE(hipMalloc(&e->buf.last_group, 2 * C * 16));   // current | next (the host swaps them after every batch)
+    e->buf.last_group_next = e->buf.last_group + C * 16;
     // (the internal symbol buffer [C][F][260416] is allocated by the first batch that needs it: the fused form never does)
     // zero history (reference: atsc.cpp:24-26,34; trellis.h:55-59)
     if (e->buf.coded) TRY_OR_FREE(hipMemset(e->buf.coded, 0, C * e->buf.coded_stride));
     TRY_OR_FREE(hipMemset(e->buf.tail, 0, C * kTail));
     TRY_OR_FREE(hipMemset(e->buf.carry, 0, C * sizeof(uint4)));
     TRY_OR_FREE(hipMemset(e->buf.span_par, 0, C * sizeof(uint4)));
-    TRY_OR_FREE(hipMemset(e->buf.last_group, 0, C * 16));
+    TRY_OR_FREE(hipMemset(e->buf.last_group, 0, 2 * C * 16));
 
     // oscillator state (double-buffered), T_0 and the per-field rotation
     for (int i = 0; i < 2; ++i) TRY_OR_FREE(hipMalloc(&e->d_osc[i], sizeof(float2) * kPaddedSyms));
@@ -243,7 +246,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
 namespace {
 
 void mark(atsc_hip_encoder* e, hipStream_t s, int idx) {
-    if (e->cur) {
+    if (e->cur && (e->mark_mask >> idx & 1u)) {
         hipEventRecord(e->cur->ev[idx], s);
         e->cur->recorded[idx] = true;
     }
@@ -409,11 +412,12 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
     if (fused) {
         // carries, then ONE kernel for trellis / map / sync / mixer / FIR: the symbols never pass through HBM; the symbol
         // tap is written only if the caller asked for it (d_sym)
+        // (the carry scan, the oscillator table of the batch and the save of the batch's last interleaved bytes are one launch:
+        // its time is reported under the oscillator stage, the scan and state stages read 0)
         mark(e, s, ATSC_HIP_STAGE_TRELLIS_SCAN);
-        launch_trellis_scan(s, e->buf, static_cast<const uint4*>(d_carry_xor), e->cfg.channels, fields);
         mark(e, s, ATSC_HIP_STAGE_OSC);
-        launch_osc_table(s, e->d_osc[e->osc_cur], e->d_osc[e->osc_cur ^ 1], e->d_osc_tab, e->scale, fields,
-                         wide ? kOscPlanes16 : kOscPlanes4096);
+        launch_scan_osc_state(s, e->buf, static_cast<const uint4*>(d_carry_xor), e->cfg.channels, fields, e->d_osc[e->osc_cur],
+                              e->d_osc[e->osc_cur ^ 1], e->d_osc_tab, e->scale, wide ? kOscPlanes16 : kOscPlanes4096);
         e->osc_cur ^= 1;
         mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
         if (wide)
@@ -434,7 +438,8 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
         if (rc) return rc;
     }
     mark(e, s, ATSC_HIP_STAGE_STATE);
-    launch_save_state(s, e->buf, e->cfg.channels, fields);
+    if (!fused) launch_save_state(s, e->buf, e->cfg.channels, fields);   // (the fused path's merged launch has done it)
+    std::swap(e->buf.last_group, e->buf.last_group_next);               // in stream order: what was saved is now the history
     mark(e, s, ATSC_HIP_NSTAGES);
     e->field_index += (uint64_t)fields;
     return static_cast<int>(hipGetLastError());
@@ -962,6 +967,17 @@ extern "C" int atsc_hip_timing_reserve(atsc_hip_encoder* e, int nslots) {
     for (auto& set : e->slots) std::fill(std::begin(set.recorded), std::end(set.recorded), false);
     e->batches = 0;
     e->cur = nullptr;
+    return ATSC_HIP_OK;
+}
+
+extern "C" int atsc_hip_timing_select(atsc_hip_encoder* e, unsigned stage_mask) {
+    if (!e) return ATSC_HIP_ERR_ARG;
+    if (!e->ev_valid) return ATSC_HIP_ERR_STATE;
+    // a stage's time runs from its own mark to the next recorded one: the mark behind a selected stage is recorded as well
+    unsigned m = 0;
+    for (int i = 0; i < ATSC_HIP_NSTAGES; ++i)
+        if (stage_mask >> i & 1u) m |= 3u << i;
+    e->mark_mask = stage_mask == ~0u ? ~0u : m;
     return ATSC_HIP_OK;
 }
 

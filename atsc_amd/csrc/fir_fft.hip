@@ -26,6 +26,7 @@
 // reference's exact fp32 recursion (offset.h:35-41), so a task (block, field, channel group) needs no
 // history and the grid is a flat list of equal tasks.
 #include "kernels.h"
+#include "front_roles.h"
 #include "iq_format.h"
 
 #include <cmath>
@@ -344,50 +345,10 @@ __global__ __launch_bounds__(kFftThreads) void k_mix_fir_fft(const uint8_t* __re
     }
 }
 
-// Oscillator table of a batch: tab[f] = T_(f0+f) for f < fields, out = T_(f0+fields)   (offset.h:35-41).
-// planes != 0: the layout of the matrix-core forms (fir_fused.hip): [f][re plane | im plane] of kPaddedSyms dwords, where
-// the dwords 2m, 2m+1 of a plane hold the positions 2m and 2m+1 as fp16 pieces of T * S (fp16's normal range; S = 4096 for
-// fir_fused.hip, kOscPlanes4096, and 16 for fir_w.hip, kOscPlanes16):
-// {Th(2m), Th(2m+1)}, {Tl(2m), Tl(2m+1)} with Th = fl16(T * S), Tl = fl16(T * S - Th).
+// Oscillator table of a batch (front_roles.h: osc_table_body).
 __global__ __launch_bounds__(256) void k_osc_table(const float2* __restrict__ in, float2* __restrict__ tab,
                                                    float2* __restrict__ out, float2 sc, int fields, int planes) {
-    // a thread owns two neighbouring table entries: the plane form packs their fp16 pieces into whole dwords (dword 2m of a
-    // plane = the two high pieces, dword 2m + 1 the two low ones), so it leaves as one 8-byte store per component and field
-    // instead of four 2-byte ones per entry; the complex form as one 16-byte store
-    static_assert(kPaddedSyms % 2 == 0, "entries come in pairs");
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= kPaddedSyms / 2) return;
-    const float4 t01 = reinterpret_cast<const float4*>(in)[m];
-    float2 t[2] = {make_float2(t01.x, t01.y), make_float2(t01.z, t01.w)};
-    float* pl = reinterpret_cast<float*>(tab);
-    const float pscale = planes == kOscPlanes16 ? 16.0f : 4096.0f;
-    for (int f = 0; f < fields; ++f) {
-        if (planes) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                _Float16 hi[2], lo[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float v = (c ? t[j].y : t[j].x) * pscale;
-                    hi[j] = (_Float16)v;
-                    lo[j] = (_Float16)(v - (float)hi[j]);
-                }
-                uint2 w;
-                w.x = (uint32_t)__builtin_bit_cast(uint16_t, hi[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, hi[1]) << 16);
-                w.y = (uint32_t)__builtin_bit_cast(uint16_t, lo[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, lo[1]) << 16);
-                *reinterpret_cast<uint2*>(pl + ((size_t)f * 2 + c) * kPaddedSyms + 2 * m) = w;
-            }
-        } else {
-            reinterpret_cast<float4*>(tab + (size_t)f * kPaddedSyms)[m] = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float t2 = __fmul_rn(t[j].y, sc.y);
-            const float t3 = __fmul_rn(t[j].x, sc.y);
-            t[j] = make_float2(__fmaf_rn(t[j].x, sc.x, -t2), __fmaf_rn(t[j].y, sc.x, t3));
-        }
-    }
-    reinterpret_cast<float4*>(out)[m] = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
+    osc_table_body(in, tab, out, sc, fields, planes, blockIdx.x * 256 + threadIdx.x);
 }
 
 hipError_t upload_fft_tables(const float* taps112) {

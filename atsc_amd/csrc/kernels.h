@@ -48,7 +48,9 @@ struct Buffers {
     uint4* cin;                              // [channel][fields*26] carries entering each part
     uint4* carry;                            // [channel] trellis state entering the batch (updated by the scan)
     uint4* span_par;                         // [channel] XOR of all parities of the batch
-    uint8_t* last_group;                     // [channel][16] last 12 interleaved bytes of the previous field
+    uint8_t* last_group;                     // [channel][16] last 12 interleaved bytes of the previous batch (what this batch's first field starts from)
+    uint8_t* last_group_next;                // the same for the NEXT batch: written by this batch's save (launch_save_state /
+                                             // launch_scan_osc_state) while the FIR may still read last_group; the host swaps the two
     int max_fields;
 };
 
@@ -61,6 +63,10 @@ void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts
 void launch_assemble(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                      int channels, int fields);
 void launch_trellis_scan(hipStream_t s, const Buffers& b, const uint4* carry_xor, int channels, int fields);
+// the fused path: carry scan + oscillator table of the batch (launch_osc_table's arguments) + save of the last interleaved bytes
+// into b.last_group_next, as ONE launch
+void launch_scan_osc_state(hipStream_t s, const Buffers& b, const uint4* carry_xor, int channels, int fields, const float2* osc_in,
+                           float2* osc_out, float2* osc_tab, float2 scale, int planes);
 void launch_span_parity(hipStream_t s, const Buffers& b, uint4* d_out, int channels, int fields);
 void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride,
                         int channels, int fields, uint64_t field_base);

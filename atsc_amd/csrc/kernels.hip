@@ -12,6 +12,7 @@
 // All byte/bit stages are bit-exact restatements of the closed forms in SURVEY.md Appendix A; the float
 // stage (fir_fft.hip) follows the reference's rounding for the oscillator recursion.
 #include "kernels.h"
+#include "front_roles.h"
 #include "trellis_bits.h"
 
 #include <cstdlib>
@@ -28,10 +29,9 @@ namespace atsc_k {
 // extracts, 8 LDS reads (four 20-byte rows) and 20 XORs; the 4-byte shift of the 160-bit register is a renaming.
 // The dropped TS sync byte (randomize.h:48) is fed as a zero, which leaves a zero state untouched, so a packet is
 // exactly 47 steps.  The code is GF(2)-linear, so the raw TS bytes are encoded and the (precomputed) parity of the
-// packet's PRBS row is added at the end.  The row lookups are the cost: lanes read random rows, so the tables sit in
-// LDS in a bank-spread image (8 copies of the 16-byte part, 8 of the 4-byte part: together the CU's whole 160 KB; the two
-// lanes of a 16-lane service group that share a copy collide only when their rows have the same parity), and nothing else
-// lives in LDS so that 16 waves per CU hide the lookup latency.
+// packet's PRBS row is added at the end.  The row lookups are the cost: lanes read random rows; the tables sit in LDS in a
+// layout in which no two lanes of a service group can meet (the kernel's own comment), 128 KB, and nothing else lives in
+// LDS: 16 waves per CU hide the lookup latency.
 //
 // k_assemble (debug tap, ATSC_HIP_FLAG_TAPS): coded[207 s + k] = ts[188 s + 1 + k] ^ prbs[187 s + k] (k < 187) followed
 // by the 20 parity bytes: a byte-shifting copy, staged through LDS rows of 212 bytes with coalesced loads and stores.
@@ -252,15 +252,7 @@ void launch_assemble(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, 
                        reinterpret_cast<const uint32_t*>(b.parity), b.coded, b.coded_stride, t.prbs188, fields);
 }
 
-// trellis helpers (canonical_group, trellis_local): trellis_bits.h
-__device__ __forceinline__ uint32_t wave_xor_inclusive(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(v, d, 64);
-        if (lane >= d) v ^= o;
-    }
-    return v;
-}
+// trellis helpers (canonical_group, trellis_local): trellis_bits.h; wave_xor_inclusive: front_roles.h
 
 // ======================================================================================= K2 interleaver
 // IL[M] = E[M - 208 (M mod 52)]  (B = 52, M = 4), E the channel's continuous RS-coded stream.
@@ -660,50 +652,40 @@ void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts
 }
 
 // ======================================================================================= K3 scan
-// One wave per channel: exclusive XOR scan over fields*26 parts, seeded with the channel's carry.
-// Lane l owns one field (26 parts) per pass of 64 fields.
+// One wave per channel (front_roles.h: trellis_scan_body).
 __global__ __launch_bounds__(64) void k_trellis_scan(const uint4* __restrict__ par, uint4* __restrict__ cin,
                                                      uint4* __restrict__ carry, uint4* __restrict__ span_par,
                                                      const uint4* __restrict__ carry_xor, int fields) {
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x;
-    uint4 init = carry[c];
-    if (carry_xor) {  // time-split hand-off: state_in = own history XOR the parities of all earlier spans
-        const uint4 x = carry_xor[c];
-        init.x ^= x.x; init.y ^= x.y; init.z ^= x.z;
+    trellis_scan_body(par, cin, carry, span_par, carry_xor, fields, blockIdx.x, threadIdx.x);
+}
+
+// The fused path's three small launches in one grid (front_roles.h): workgroups [0, channels) scan a channel's parities
+// (first wave), the next ones fill the oscillator table of the batch, the last ones copy the batch's last interleaved bytes
+// into the NEXT history buffer (the FIR behind this launch still reads the current one).
+__global__ __launch_bounds__(256) void k_scan_osc_state(const uint4* __restrict__ par, uint4* __restrict__ cin,
+                                                        uint4* __restrict__ carry, uint4* __restrict__ span_par,
+                                                        const uint4* __restrict__ carry_xor, int channels, int fields,
+                                                        const float2* __restrict__ osc_in, float2* __restrict__ osc_tab,
+                                                        float2* __restrict__ osc_out, float2 sc, int planes,
+                                                        const uint8_t* __restrict__ il, size_t il_stride,
+                                                        uint8_t* __restrict__ last_group_next) {
+    constexpr int kOscBlocks = (kPaddedSyms / 2 + 255) / 256;
+    const int b = blockIdx.x;
+    if (b < channels) {
+        if (threadIdx.x < 64) trellis_scan_body(par, cin, carry, span_par, carry_xor, fields, b, threadIdx.x);
+    } else if (b < channels + kOscBlocks) {
+        osc_table_body(osc_in, osc_tab, osc_out, sc, fields, planes, (b - channels) * 256 + threadIdx.x);
+    } else {
+        save_last_group_body(il, il_stride, last_group_next, channels, fields, (b - channels - kOscBlocks) * 256 + threadIdx.x);
     }
-    uint32_t run[3] = {init.x, init.y, init.z};
-    for (int f0 = 0; f0 < fields; f0 += 64) {
-        const int f = f0 + lane;
-        const bool on = f < fields;
-        const uint4* pp = par + ((size_t)c * fields + (on ? f : 0)) * kParts;
-        uint32_t tot[3] = {0, 0, 0};
-        if (on) {
-            for (int p = 0; p < kParts; ++p) {
-                const uint4 v = pp[p];
-                tot[0] ^= v.x; tot[1] ^= v.y; tot[2] ^= v.z;
-            }
-        }
-        uint32_t pre[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const uint32_t inc = wave_xor_inclusive(tot[k], lane);
-            pre[k] = run[k] ^ inc ^ tot[k];  // exclusive prefix for this lane's field
-            run[k] ^= __shfl(inc, 63, 64);   // all lanes: total of this pass
-        }
-        if (on) {
-            uint4* co = cin + ((size_t)c * fields + f) * kParts;
-            for (int p = 0; p < kParts; ++p) {
-                co[p] = make_uint4(pre[0], pre[1], pre[2], 0);
-                const uint4 v = pp[p];
-                pre[0] ^= v.x; pre[1] ^= v.y; pre[2] ^= v.z;
-            }
-        }
-    }
-    if (lane == 0) {
-        carry[c] = make_uint4(run[0], run[1], run[2], 0);
-        span_par[c] = make_uint4(run[0] ^ init.x, run[1] ^ init.y, run[2] ^ init.z, 0);
-    }
+}
+
+void launch_scan_osc_state(hipStream_t s, const Buffers& b, const uint4* carry_xor, int channels, int fields, const float2* osc_in,
+                           float2* osc_out, float2* osc_tab, float2 scale, int planes) {
+    constexpr int kOscBlocks = (kPaddedSyms / 2 + 255) / 256;
+    const unsigned grid = (unsigned)(channels + kOscBlocks + (3 * channels + 255) / 256);
+    hipLaunchKernelGGL(k_scan_osc_state, dim3(grid), dim3(256), 0, s, b.par, b.cin, b.carry, b.span_par, carry_xor, channels, fields,
+                       osc_in, osc_tab, osc_out, scale, planes, b.il, b.il_stride, b.last_group_next);
 }
 
 void launch_trellis_scan(hipStream_t s, const Buffers& b, const uint4* carry_xor, int channels, int fields) {
@@ -833,16 +815,12 @@ void launch_trellis_map(hipStream_t s, const DeviceTables& t, const Buffers& b, 
 
 // ======================================================================================= K7 state save
 __global__ __launch_bounds__(64) void k_save_state(const uint8_t* __restrict__ il, size_t il_stride,
-                                                   uint8_t* __restrict__ last_group, int channels, int fields) {
-    const int i = blockIdx.x * 64 + threadIdx.x;  // (channel, dword) of the last 12 interleaved bytes
-    const int c = i / 3, w = i - 3 * c;
-    if (c >= channels) return;
-    const uint32_t* lg = reinterpret_cast<const uint32_t*>(il + (size_t)c * il_stride + (size_t)fields * kFieldCoded - 12);
-    reinterpret_cast<uint32_t*>(last_group + (size_t)c * 16)[w] = lg[w];
+                                                   uint8_t* __restrict__ last_group_next, int channels, int fields) {
+    save_last_group_body(il, il_stride, last_group_next, channels, fields, blockIdx.x * 64 + threadIdx.x);
 }
 
 void launch_save_state(hipStream_t s, const Buffers& b, int channels, int fields) {
-    hipLaunchKernelGGL(k_save_state, dim3((3 * channels + 63) / 64), dim3(64), 0, s, b.il, b.il_stride, b.last_group,
+    hipLaunchKernelGGL(k_save_state, dim3((3 * channels + 63) / 64), dim3(64), 0, s, b.il, b.il_stride, b.last_group_next,
                        channels, fields);
 }
 

@@ -292,6 +292,12 @@ int atsc_hip_last_timings(atsc_hip_encoder* enc, float* ms /* [ATSC_HIP_NSTAGES]
 int atsc_hip_timing_reserve(atsc_hip_encoder* enc, int nslots);
 /* ... and read batch `batch` (0-based since the last reserve; must still be in the ring) afterwards. */
 int atsc_hip_batch_timings(atsc_hip_encoder* enc, int batch, float* ms /* [ATSC_HIP_NSTAGES] */);
+/* Which stages the following batches time (bit i = ATSC_HIP_STAGE_i; ~0u = all, the default).  An event between two kernels
+ * costs the stream about 5 us of idle time on this part, eight of them 1 % of a 64 x 64 step: a timed region that needs one
+ * kernel's duration selects that stage alone (its mark and the one behind it are recorded), the other stages read 0.  The
+ * fused path launches the carry scan, the oscillator table and the state save as ONE kernel, reported under
+ * ATSC_HIP_STAGE_OSC.  No reference counterpart (measurement). */
+int atsc_hip_timing_select(atsc_hip_encoder* enc, unsigned stage_mask);
 
 /* Constant tables as the library built them (host copies), for table parity tests:
  * which: 0 = 112 FIR taps (float), 1 = oscillator T0 (261248 complex64), 2 = scale (2 floats),
