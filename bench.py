@@ -161,6 +161,8 @@ def parse_args(argv=None):
     ap.add_argument("--sustain-seconds", type=float, default=2.0,
                     help="after the headline loop: this many seconds of back-to-back steps, reported as `sustained` (0 = skip)")
     ap.add_argument("--verbose-line", action="store_true", help="keep the replayed counter summaries in the line (long)")
+    ap.add_argument("--settle-seconds", type=float, default=0.12,
+                    help="untimed steps in front of the warm-up until the power manager has settled (0: none)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the legs behind the headline loop (sustained run, fp32-form run, in-run IQ error): profiler passes")
     ap.add_argument("--rccl", action="store_true",
@@ -508,6 +510,16 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         torch.cuda.synchronize()
         per_ch = F * FIELD_SYMBOLS * 8
         first_iq = {c: iq[c * per_ch:(c + 1) * per_ch].cpu().numpy().view("float32") for c in check_channels}
+    # Settle: the first ~15 steps after the GPU leaves idle run 5-25 % slow (the power manager overshoots, throttles, then
+    # settles: per-step FIR times 1.97, 2.42, 2.30, 2.16, 2.07 ... 1.87 ms from a cold start); a modulator is a continuous load,
+    # so the W warm-up steps and the K timed steps start from the settled state whatever W is.  Untimed, reported.
+    settle_steps = 0
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < args.settle_seconds:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        settle_steps += 8
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -522,6 +534,8 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     rk.barrier()
     elapsed = rk.max_over_ranks(time.perf_counter() - t0, "cuda")
     fir_timed = [enc.batch_timings(b) for b in range(args.steps)]
+    if os.environ.get("ATSC_BENCH_DEBUG"):
+        print("fir ms per timed step:", [round(t["mix_fir"], 4) for t in fir_timed], file=sys.stderr)
     # every stage timed, right behind the timed region (not part of `value`)
     n_all = max(5, min(args.steps, 20))
     enc.timing_select(None)
@@ -622,6 +636,7 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
         "realtime_channels_per_gpu": round(msym_s / SYMBOL_RATE_MSPS / rk.world, 1),
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "stage_ms_from": "mix_fir: HIP events of the timed region (the only events it records); others: every-stage pass behind it",
+        "settle": {"untimed_steps_before_warmup": settle_steps, "why": "first ~15 steps after idle run 5-25 % slow (power transient)"},
         "roofline": roofline,
         "roofline_other_stages": stages,
     }
