@@ -486,19 +486,20 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     else:
         iq_bytes = sample_bytes
     iq = torch.empty(C_ * F * FIELD_SYMBOLS * iq_bytes * up, dtype=torch.uint8, device="cuda")
-    step_no = [-args.warmup]
+    rec = {"on": False, "k": 0}     # the resampler's events are recorded in the timed region only
 
     def step():
         enc.encode_batch(ts.data_ptr(), F, sym.data_ptr() if args.symbol_tap else None, iq.data_ptr(), stream)
         if rs is not None:
-            k = step_no[0]
-            step_no[0] += 1
-            if k >= 0:
+            k = rec["k"]
+            on = rec["on"] and k < args.steps
+            if on:
                 rs_ev[k][0].record()
                 rs_samples.append(rs.out_count(n_in))
             rs.resample(iq.data_ptr(), n_in, n_in, rs_out.data_ptr(), n_out, stream)
-            if k >= 0:
+            if on:
                 rs_ev[k][1].record()
+                rec["k"] = k + 1
 
     # the handle's very first batch (zero history, field index 0): two channels of its IQ are kept on the host and
     # compared with the CPU checker after the timed region (`iq_max_abs_error_vs_oracle`)
@@ -527,12 +528,14 @@ def bench_channels(args, rk, torch, atsc_amd, fmt, form, sample_bytes):
     enc.timing_select(("mix_fir",))      # the timed region times the dominant kernel only
     rk.barrier()
     torch.cuda.synchronize()
+    rec["on"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     rk.barrier()
     elapsed = rk.max_over_ranks(time.perf_counter() - t0, "cuda")
+    rec["on"] = False
     fir_timed = [enc.batch_timings(b) for b in range(args.steps)]
     if os.environ.get("ATSC_BENCH_DEBUG"):
         print("fir ms per timed step:", [round(t["mix_fir"], 4) for t in fir_timed], file=sys.stderr)
