@@ -100,7 +100,7 @@ extern "C" const char* atsc_hip_error_string(int code) {
 static int destroy_impl(atsc_hip_encoder* e) {
     if (!e) return 0;
     hipSetDevice(e->cfg.device);
-    hipFree(e->buf.coded); hipFree(e->buf.tail); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
+    hipFree(e->buf.coded); hipFree(std::min(e->buf.tail, e->buf.tail_next)); hipFree(e->buf.parity); hipFree(e->buf.il); hipFree(e->buf.par); hipFree(e->buf.cin);
     hipFree(e->buf.carry); hipFree(e->buf.span_par);
     hipFree(std::min(e->buf.last_group, e->buf.last_group_next));   // one allocation, two halves that swap roles
     hipFree(e->d_sym); hipFree(e->d_osc[0]); hipFree(e->d_osc[1]); hipFree(e->d_osc0); hipFree(e->d_osc_tab); hipFree(e->d_tables);
@@ -207,7 +207,8 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     e->buf.il_stride = align_up(F * kFieldCoded, 256);
     e->sym_stride = F * kFieldSyms;
     if (cfg->flags & ATSC_HIP_FLAG_TAPS) TRY_OR_FREE(hipMalloc(&e->buf.coded, C * e->buf.coded_stride));
-    TRY_OR_FREE(hipMalloc(&e->buf.tail, C * kTail));
+    TRY_OR_FREE(hipMalloc(&e->buf.tail, 2 * C * kTail));   // current | next (swapped behind every interleaver launch)
+    e->buf.tail_next = e->buf.tail + C * kTail;
     TRY_OR_FREE(hipMalloc(&e->buf.parity, C * F * kPackets * 32));
     TRY_OR_FREE(hipMalloc(&e->buf.il, C * e->buf.il_stride));
     TRY_OR_FREE(hipMalloc(&e->buf.par, C * F * kParts * sizeof(uint4)));
@@ -219,7 +220,7 @@ static int create_impl(const atsc_hip_config* cfg, atsc_hip_encoder** out) {
     // (the internal symbol buffer [C][F][260416] is allocated by the first batch that needs it: the fused form never does)
     // zero history (reference: atsc.cpp:24-26,34; trellis.h:55-59)
     if (e->buf.coded) TRY_OR_FREE(hipMemset(e->buf.coded, 0, C * e->buf.coded_stride));
-    TRY_OR_FREE(hipMemset(e->buf.tail, 0, C * kTail));
+    TRY_OR_FREE(hipMemset(e->buf.tail, 0, 2 * C * kTail));
     TRY_OR_FREE(hipMemset(e->buf.carry, 0, C * sizeof(uint4)));
     TRY_OR_FREE(hipMemset(e->buf.span_par, 0, C * sizeof(uint4)));
     TRY_OR_FREE(hipMemset(e->buf.last_group, 0, 2 * C * 16));
@@ -287,6 +288,7 @@ int run_front(atsc_hip_encoder* e, const uint8_t* d_ts, int fields, hipStream_t 
     if (e->buf.coded) launch_assemble(s, e->dtab, d_ts, ts_stride, e->buf, C, fields);
     mark(e, s, ATSC_HIP_STAGE_INTERLEAVE);
     launch_interleave(s, e->dtab, d_ts, ts_stride, e->buf, C, fields);  // + the per-part trellis parities
+    std::swap(e->buf.tail, e->buf.tail_next);   // in stream order: the tail the launch wrote is now the history
     return static_cast<int>(hipGetLastError());
 }
 

@@ -42,6 +42,8 @@ struct Buffers {
     // [channel] strides in bytes
     uint8_t* coded;  size_t coded_stride;   // debug tap only (ATSC_HIP_FLAG_TAPS): per channel [kTail unused | fields*64584]
     uint8_t* tail;                           // [channel][kTail]: last 10608 RS-coded bytes of the previous batch
+    uint8_t* tail_next;                      // the same of THIS batch, written by k_interleave while other workgroups still read `tail`;
+                                             // the host swaps the two behind launch_interleave
     uint4* parity;                           // [channel][fields*312] x 32 B: RS parity per packet (20 bytes used)
     uint8_t* il;     size_t il_stride;      // per channel: fields*64584, transmission order
     uint4* par;                              // [channel][fields*26] parities (3 words used)
@@ -56,7 +58,8 @@ struct Buffers {
 
 void launch_rand_rs(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                     int channels, int fields);
-// interleaver + per-part trellis parities straight from TS + parity (+ the saved coded tail); then refreshes the tail
+// interleaver + per-part trellis parities straight from TS + parity (+ the saved coded tail b.tail); leaves the batch's own
+// tail in b.tail_next: the caller swaps the two pointers afterwards
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
                        int channels, int fields);
 // debug tap: materialises the RS-coded stream b.coded (not needed by the path itself)

@@ -316,6 +316,7 @@ __device__ __forceinline__ uint64_t scalar_addr(uint64_t v) {
 
 __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __restrict__ ts, size_t ts_stride,
                                                            const uint8_t* __restrict__ parity, const uint8_t* __restrict__ tail,
+                                                           uint8_t* __restrict__ tail_next,
                                                            const uint8_t* __restrict__ prbs_rows, uint8_t* __restrict__ il,
                                                            size_t il_stride, uint32_t* __restrict__ par, int fields,
                                                            int fields_per_block) {
@@ -617,21 +618,25 @@ __global__ __launch_bounds__(kIlThreads) void k_interleave(const uint8_t* __rest
         }
     }
     fold(kCkPerField - 1, f1 - 1);      // (behind the last chunk's closing barrier)
-}
-
-// Coded tail of the batch (the last 10608 RS-coded bytes) for the next batch's first block and for state export.
-__global__ __launch_bounds__(256) void k_save_tail(const uint8_t* __restrict__ ts, size_t ts_stride,
-                                                   const uint8_t* __restrict__ parity, const uint8_t* __restrict__ prbs,
-                                                   uint8_t* __restrict__ tail, int fields) {
-    const int c = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kTail) return;
-    const int total = fields * kPackets;
-    const int o = total * kSegCoded - kTail + i;   // >= 0: a batch is at least one field
-    const int q = o / kSegCoded, r = o - q * kSegCoded;
-    const uint8_t v = r < 187 ? (uint8_t)(ts[(size_t)c * ts_stride + (size_t)q * kTsBytes + 1 + r] ^ prbs[(q % kPackets) * 187 + r])
-                              : parity[((size_t)c * total + q) * 32 + 3 + (r - 187)];
-    tail[(size_t)c * kTail + i] = v;
+    // The workgroup that ends the channel's batch leaves the coded tail for the next batch (and for state export): the last
+    // 10608 RS-coded bytes = the last 51 packets and the last 51 bytes of the one before, all of them rows of the last chunk,
+    // which sits in half 1 of the ring (an odd chunk; nothing was committed behind it).  It goes to the OTHER tail buffer --
+    // the workgroup of the channel's first fields may still be reading the current one -- and the host swaps the two.
+    if (f1 == fields) {
+        const uint8_t* rows = reinterpret_cast<const uint8_t*>(s_pkt + kCkPk * kIlRowDw);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(tail_next + (size_t)c * kTail);
+        constexpr int kFirst = kCkPk * kSegCoded - kTail;      // 156: offset of the tail in the chunk's coded bytes
+        for (int j = tid; j < kTail / 4; j += kIlThreads) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int o = kFirst + 4 * j + i;
+                const int row = o / kSegCoded, b = o - row * kSegCoded;
+                v |= (uint32_t)rows[row * (kIlRowDw * 4) + b] << (8 * i);
+            }
+            dst[j] = v;
+        }
+    }
 }
 
 void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts, size_t ts_stride, const Buffers& b,
@@ -644,11 +649,9 @@ void launch_interleave(hipStream_t s, const DeviceTables& t, const uint8_t* d_ts
     int fpb = (int)(((long)channels * fields + kIlGridTarget - 1) / kIlGridTarget);
     fpb = fpb < 1 ? 1 : (fpb > 16 ? 16 : fpb);
     dim3 grid((fields + fpb - 1) / fpb, channels);
+    // (the batch's own coded tail is written into b.tail_next by the workgroup that ends each channel; the caller swaps)
     hipLaunchKernelGGL(k_interleave, grid, dim3(kIlThreads), 0, s, d_ts, ts_stride, reinterpret_cast<const uint8_t*>(b.parity),
-                       b.tail, t.prbs_rows, b.il, b.il_stride, reinterpret_cast<uint32_t*>(b.par), fields, fpb);
-    // the tail is consumed above and replaced by this batch's own (stream order)
-    hipLaunchKernelGGL(k_save_tail, dim3((kTail + 255) / 256, channels), dim3(256), 0, s, d_ts, ts_stride,
-                       reinterpret_cast<const uint8_t*>(b.parity), t.prbs, b.tail, fields);
+                       b.tail, b.tail_next, t.prbs_rows, b.il, b.il_stride, reinterpret_cast<uint32_t*>(b.par), fields, fpb);
 }
 
 // ======================================================================================= K3 scan
