@@ -411,6 +411,7 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
         if (rc) return rc;
     }
     uint8_t* sym = d_sym ? d_sym : e->d_sym;
+    bool fir_stop_recorded = false;
     if (fused) {
         // carries, then ONE kernel for trellis / map / sync / mixer / FIR: the symbols never pass through HBM; the symbol
         // tap is written only if the caller asked for it (d_sym)
@@ -421,17 +422,26 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
         launch_scan_osc_state(s, e->buf, static_cast<const uint4*>(d_carry_xor), e->cfg.channels, fields, e->d_osc[e->osc_cur],
                               e->d_osc[e->osc_cur ^ 1], e->d_osc_tab, e->scale, wide ? kOscPlanes16 : kOscPlanes4096);
         e->osc_cur ^= 1;
-        mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
+        // the mixer + FIR kernel's two events ride on its own dispatch when both are wanted (the usual case of a timed region)
+        KernelEvents kev{};
+        const bool own_events = !wide && e->cur && (e->mark_mask >> ATSC_HIP_STAGE_MIX_FIR & 1u) && (e->mark_mask >> ATSC_HIP_STAGE_STATE & 1u);
+        if (own_events) {
+            kev = {e->cur->ev[ATSC_HIP_STAGE_MIX_FIR], e->cur->ev[ATSC_HIP_STAGE_STATE]};
+            e->cur->recorded[ATSC_HIP_STAGE_MIX_FIR] = e->cur->recorded[ATSC_HIP_STAGE_STATE] = true;
+        } else {
+            mark(e, s, ATSC_HIP_STAGE_MIX_FIR);
+        }
         if (wide)
             launch_mix_fir_wide(s, e->dtab, e->buf, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms,
                                 reinterpret_cast<const float*>(e->d_osc_tab), e->cfg.channels, fields, e->field_index);
         else
         launch_mix_fir_fused(s, e->dtab, e->buf, d_sym, sym_stride, d_iq, (size_t)fields * kFieldSyms * e->upsample,
                              reinterpret_cast<const float*>(e->d_osc_tab), e->cfg.channels, fields, e->field_index,
-                             e->iq_format, e->upsample);
+                             e->iq_format, e->upsample, own_events ? &kev : nullptr);
         rc = static_cast<int>(hipGetLastError());
         if (rc) return rc;
         e->sym_internal = false;
+        fir_stop_recorded = own_events;
     } else {
         rc = run_back(e, static_cast<const uint4*>(d_carry_xor), fields, sym, sym_stride, s);
         if (rc) return rc;
@@ -439,7 +449,7 @@ static int finish_impl(atsc_hip_encoder* e, const void* d_carry_xor, uint8_t* d_
         rc = run_mix_fir(e, sym, sym_stride, d_iq, fields, s);
         if (rc) return rc;
     }
-    mark(e, s, ATSC_HIP_STAGE_STATE);
+    if (!fir_stop_recorded) mark(e, s, ATSC_HIP_STAGE_STATE);
     if (!fused) launch_save_state(s, e->buf, e->cfg.channels, fields);   // (the fused path's merged launch has done it)
     std::swap(e->buf.last_group, e->buf.last_group_next);               // in stream order: what was saved is now the history
     mark(e, s, ATSC_HIP_NSTAGES);

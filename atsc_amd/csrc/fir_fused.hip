@@ -32,6 +32,8 @@
 //   * C (32x32 fp32) goes through a wave-private LDS image [channel][32 outputs] in the OUTPUT sample format and leaves
 //     as whole 128-byte lines, 16 bytes per lane, spread over the next tile's MFMA sequence.
 // No workgroup barriers; waves are independent (LDS operations of a wave execute in program order).
+#include <hip/hip_ext.h>
+
 #include "iq_format.h"
 #include "kernels.h"
 #include "trellis_bits.h"
@@ -726,29 +728,34 @@ int pick_rounds(int ch_groups, int fields, int startup_tiles, int resident) {
     return rounds;
 }
 
+// ev: the dispatch itself carries the two timing events (hipExtLaunchKernelGGL: start and stop come from the kernel's own
+// completion signal), so timing this kernel puts no event packets -- about 5 us of idle stream each -- around it
 template <int FMT, bool FUSED, int UP>
-void launch_mm(hipStream_t s, FirArgs a) {
+void launch_mm(hipStream_t s, FirArgs a, const KernelEvents* ev) {
     a.ch_groups = (a.channels + kFusedGroup - 1) / kFusedGroup;
     a.rounds = pick_rounds(a.ch_groups, a.fields, FUSED ? 12 : 4, UP == 1 ? 2048 : 1024);
     a.runs_per_field = (kTiles + kRound * a.rounds - 1) / (kRound * a.rounds);
     const long tasks = (long)a.runs_per_field * a.ch_groups * a.fields;
     const unsigned grid = (unsigned)((tasks + kWaves - 1) / kWaves);
-    hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED, UP>), dim3(grid), dim3(64 * kWaves), 0, s, a);
+    if (ev)
+        hipExtLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED, UP>), dim3(grid), dim3(64 * kWaves), 0, s, ev->start, ev->stop, 0, a);
+    else
+        hipLaunchKernelGGL((k_mix_fir_mm<FMT, FUSED, UP>), dim3(grid), dim3(64 * kWaves), 0, s, a);
 }
 
 template <bool FUSED, int UP>
-void launch_fmt(hipStream_t s, const FirArgs& a, int iq_format) {
+void launch_fmt(hipStream_t s, const FirArgs& a, int iq_format, const KernelEvents* ev) {
     switch (iq_format) {
-        case kIqCs16: launch_mm<kIqCs16, FUSED, UP>(s, a); break;
-        case kIqCs8: launch_mm<kIqCs8, FUSED, UP>(s, a); break;
-        default: launch_mm<kIqCf32, FUSED, UP>(s, a); break;
+        case kIqCs16: launch_mm<kIqCs16, FUSED, UP>(s, a, ev); break;
+        case kIqCs8: launch_mm<kIqCs8, FUSED, UP>(s, a, ev); break;
+        default: launch_mm<kIqCf32, FUSED, UP>(s, a, ev); break;
     }
 }
 
 template <bool FUSED>
-void launch_up(hipStream_t s, const FirArgs& a, int iq_format, int upsample) {
-    if (upsample == 2) launch_fmt<FUSED, 2>(s, a, iq_format);
-    else launch_fmt<FUSED, 1>(s, a, iq_format);
+void launch_up(hipStream_t s, const FirArgs& a, int iq_format, int upsample, const KernelEvents* ev = nullptr) {
+    if (upsample == 2) launch_fmt<FUSED, 2>(s, a, iq_format, ev);
+    else launch_fmt<FUSED, 1>(s, a, iq_format, ev);
 }
 
 }  // namespace
@@ -768,7 +775,7 @@ void launch_mix_fir_mfma(hipStream_t s, const uint8_t* d_sym, size_t sym_stride,
 
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                           size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
-                          int iq_format, int upsample) {
+                          int iq_format, int upsample, const KernelEvents* ev) {
     FirArgs a{};
     a.sym = d_sym;   // optional symbol tap
     a.sym_stride = sym_stride;
@@ -783,7 +790,7 @@ void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b
     a.last_group = b.last_group;
     a.fsync = t.fsync;
     a.parity0 = (unsigned)(field_base & 1);
-    launch_up<true>(s, a, iq_format, upsample);
+    launch_up<true>(s, a, iq_format, upsample, ev);
 }
 
 }  // namespace atsc_k

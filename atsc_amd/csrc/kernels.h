@@ -102,9 +102,11 @@ void build_mm_operand(const float* taps112, const float* taps_half112, std::vect
 hipError_t download_mm_tables(uint16_t* out);
 // The same with the trellis / map / sync stage fused in: symbols are regenerated from b.il + b.cin inside the kernel and
 // never pass through HBM; d_sym (the symbol tap) may be NULL.  Replaces launch_trellis_map + launch_mix_fir_mfma.
+// ev != NULL: the kernel's own dispatch records ev->start / ev->stop (no event packets around it).
+struct KernelEvents { hipEvent_t start, stop; };
 void launch_mix_fir_fused(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
                           size_t iq_stride, const float* osc_planes, int channels, int fields, uint64_t field_base,
-                          int iq_format, int upsample);
+                          int iq_format, int upsample, const KernelEvents* ev = nullptr);
 // The fused kernel with the oscillator folded into the tap operand (fir_w.hip): 64 channels per wave task, complex64 output,
 // one sample per symbol.  osc_planes: launch_osc_table(..., kOscPlanes16).
 void launch_mix_fir_wide(hipStream_t s, const DeviceTables& t, const Buffers& b, uint8_t* d_sym, size_t sym_stride, void* d_iq,
