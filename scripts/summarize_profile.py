@@ -66,7 +66,7 @@ if fir and "FETCH_SIZE" in mean[fir] and "WRITE_SIZE" in mean[fir]:
 #   valu_issue          = 4 x SQ_INSTS_VALU / (4 SIMDs x CU-cycles)   (a wave64 vector instruction holds its SIMD 4 cycles; MFMAs longer)
 #   mfma_busy           = SQ_VALU_MFMA_BUSY_CYCLES / (4 x CU-cycles)
 stage_of = {"k_rs_parity": "rand_rs", "k_interleave": "interleave", "k_trellis_scan": "trellis_scan", "k_trellis_map": "trellis_map",
-            "k_osc_table": "osc_table", "k_mix_fir": "mix_fir"}
+            "k_osc_table": "osc_table", "k_scan_osc_state": "osc_table", "k_mix_fir": "mix_fir"}
 util = {}
 for k in ours:
     m = mean[k]
