@@ -433,3 +433,30 @@ def test_null_driver_streams_option(torch_cuda, tmp_path):
     r = json.loads(out.stdout)
     assert r["streams"] == 16 and r["fir_form"] == atsc_amd.FIR_FUSED
     assert r["fields"] == 16 * 9 and r["iq_bytes"] == 16 * 9 * FIELD_SYMBOLS * 4
+
+
+def test_timing_select_times_the_chosen_stage_only(torch_cuda):
+    """atsc_hip_timing_select: with the mixer + FIR stage alone selected a batch records that kernel's two events (on the fused
+    path they ride on the kernel's own dispatch) and every other stage reads 0; with everything selected the front stages have
+    times again; a handle without the timing flag refuses the call."""
+    torch = torch_cuda
+    C_, nf = 16, 2
+    ts = torch.from_numpy(np.concatenate([ts_mt(40 + c, nf) for c in range(C_)])).cuda()
+    iq = torch.empty((C_, nf * FIELD_SYMBOLS), dtype=torch.complex64, device="cuda")
+    enc = atsc_amd.Encoder(channels=C_, max_fields=nf, timing=True)
+    stream = torch.cuda.current_stream().cuda_stream
+    enc.timing_reserve(4)
+    enc.timing_select(("mix_fir",))
+    enc.encode_batch(ts.data_ptr(), nf, None, iq.data_ptr(), stream)
+    enc.timing_select(None)
+    enc.encode_batch(ts.data_ptr(), nf, None, iq.data_ptr(), stream)
+    torch.cuda.synchronize()
+    only, every = enc.batch_timings(0), enc.batch_timings(1)
+    assert enc.fir_form() == atsc_amd.FIR_FUSED
+    assert only["mix_fir"] > 0 and all(v == 0 for k, v in only.items() if k != "mix_fir"), only
+    assert every["mix_fir"] > 0 and every["rand_rs"] > 0 and every["interleave"] > 0 and every["osc_table"] > 0, every
+    assert abs(only["mix_fir"] - every["mix_fir"]) < 0.5 * every["mix_fir"]
+    plain = atsc_amd.Encoder(channels=1, max_fields=1)
+    with pytest.raises(atsc_amd.AtscHipError) as ei:
+        plain.timing_select(("mix_fir",))
+    assert ei.value.code == atsc_amd.ERR_STATE
